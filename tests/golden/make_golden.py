@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by importing the UNMODIFIED
+reference (/root/reference/OFDM.py) in the build container.
+
+Run from anywhere:  python tests/golden/make_golden.py
+It never runs on the GPU box (the reference does not travel); the .npz files it
+writes are data only: input sample streams and the reference's outputs.
+
+Recipe: the reference imports three modules that are not
+installed here (sounddevice, IPython.display, pyldpc -- none is used by the
+receive path) and opens 'handouts/…' with a lower-case name, so it is imported
+from a temporary scratch directory holding empty stand-in modules for those
+three imports and symlinks to the reference's data directories.  Nothing in
+/root/reference is modified and no reference source is copied.
+"""
+import contextlib
+import hashlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+from oracle import gf3_oracle as orc   # tables + stream layout helpers only  # noqa: E402
+
+
+def _scratch():
+    d = tempfile.mkdtemp(prefix="gf3ref_")
+    st = os.path.join(d, "stubs")
+    os.makedirs(os.path.join(st, "IPython"))
+    open(os.path.join(st, "sounddevice.py"), "w").write(
+        "class _D:\n    channels = 1\ndefault = _D()\n"
+        "def play(*a, **k): pass\ndef wait(): pass\n"
+        "def playrec(*a, **k): raise RuntimeError('no audio device')\n"
+        "def rec(*a, **k): raise RuntimeError('no audio device')\n")
+    open(os.path.join(st, "IPython", "__init__.py"), "w").write("")
+    open(os.path.join(st, "IPython", "display.py"), "w").write(
+        "class Audio:\n    def __init__(self, *a, **k): pass\n")
+    open(os.path.join(st, "pyldpc.py"), "w").write(
+        "def _na(*a, **k): raise NotImplementedError('pyldpc absent')\n"
+        "make_ldpc = encode = decode = get_message = _na\n")
+    os.symlink(os.path.join(REF, "Handouts"), os.path.join(d, "handouts"))
+    os.symlink(os.path.join(REF, "input_Files"), os.path.join(d, "input_files"))
+    os.symlink(os.path.join(REF, "received_signals"), os.path.join(d, "received_signals"))
+    os.makedirs(os.path.join(d, "plots"))
+    os.makedirs(os.path.join(d, "output_files"))
+    return d, st
+
+
+def import_reference():
+    d, st = _scratch()
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    sys.path[:0] = [st, REF]
+    os.chdir(d)
+    import OFDM  # noqa
+    return OFDM
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def reparam(obj, N, CP, P, D, lo, hi, pts, bits, known):
+    """Appendix B attribute overrides on a constructed reference object."""
+    K = N // 2 - 1
+    obj.ofdm_symbol_size = N
+    obj.K = K
+    obj.cp_length = CP
+    obj.lowest_bin, obj.highest_bin = lo, hi
+    obj.carriers = np.arange(1, K + 1)
+    obj.data_carriers = np.arange(lo, hi)
+    obj.data_carriers_per_symbol = len(obj.data_carriers)
+    obj.unused_carriers = np.delete(obj.carriers, obj.data_carriers - 1)
+    obj.packet_length = D
+    obj.no_pilots = P
+    obj.L = K + 1
+    obj.chirp_length = 5 * (N + CP)
+    obj.mapping_table = {tuple(int(x) for x in b): complex(c) for b, c in zip(bits, pts)}
+    obj.mu = bits.shape[1]
+    obj.data_bits_per_symbol = obj.data_carriers_per_symbol * obj.mu
+    obj.bits_per_symbol = K * obj.mu
+    obj.known_sequence = np.asarray(known, dtype=np.int64)
+    return obj
+
+
+def ref_stages(OFDM, rx, r):
+    """Run the reference receive chain stage by stage, recording the slope that
+    equalise() computes internally (np.polyfit outputs)."""
+    slopes = []
+    real_polyfit = np.polyfit
+
+    def spy(x, y, deg, *a, **k):
+        out = real_polyfit(x, y, deg, *a, **k)
+        slopes.append(out[0])
+        return out
+
+    zeros = rx.chirp_method(r)
+    sym_cp = rx.get_symbols(r, zeros)
+    X = np.fft.fft(rx.remove_cp(sym_cp))
+    data, st, en = rx.get_data(X)
+    np.polyfit = spy
+    try:
+        eq, Hs, He, Hest = rx.equalise(data, st, en)
+    finally:
+        np.polyfit = real_polyfit
+    eq_d = eq[:, rx.data_carriers - 1]
+    bits_par, hard = rx.demap(eq_d)
+    bits = rx.PS(bits_par)
+    return dict(peaks=np.flatnonzero(zeros), eq=eq_d, Hs=Hs, He=He,
+                slope=np.array(slopes), bits=bits.astype(np.uint8), Hest=Hest,
+                X=X)
+
+
+def split_insert_gaps(tx, p, gaps, lead, tail):
+    """The reference stream has no gaps; cut it at the packet boundaries (layout
+    of send_to_stream) and insert zero runs so sync has something to find."""
+    F = (len(tx) - p.Lc) // p.frame_len
+    assert F * p.frame_len + p.Lc == len(tx)
+    parts = [np.zeros(lead)]
+    for f in range(F):
+        parts += [np.zeros(int(gaps[f])), tx[f * p.frame_len:(f + 1) * p.frame_len]]
+    parts += [tx[F * p.frame_len:], np.zeros(tail)]
+    return np.concatenate(parts)
+
+
+def drift_awgn(r, eps, sigma, seed):
+    """Sample-clock offset (linear interpolation at t*(1+eps)) + white noise: gives
+    the equaliser a real phase slope and wrapped pilot phases to work on."""
+    t = np.arange(len(r)) * (1.0 + eps)
+    out = np.interp(t, np.arange(len(r)), r, right=0.0)
+    return out + sigma * np.random.RandomState(seed).randn(len(r))
+
+
+def make_loopback(OFDM, name, N, CP, P, D, F, mu, seed, channel=None, gaps=None, lead=37, tail=5,
+                  drift=None):
+    pts, bits_tbl = orc.qpsk_table() if mu == 2 else orc.square_qam_table(mu)
+    K = N // 2 - 1
+    lo, hi = 1, K
+    known = orc.load_known_bits(os.path.join(REF, "Handouts", "random_bits.txt"), max(K * mu, 4096))
+    p = orc.RxParams(N=N, CP=CP, P=P, D=D, lo=lo, hi=hi, const_points=pts,
+                     const_bits=bits_tbl, known_bits=known)
+    tx = reparam(OFDM.transmitter(mode="A1", encoding="None", no_pilots=P, packet_length=D),
+                 N, CP, P, D, lo, hi, pts, bits_tbl, known)
+    rx = reparam(OFDM.receiver(mode="A1", encoding="None", no_pilots=P, packet_length=D),
+                 N, CP, P, D, lo, hi, pts, bits_tbl, known)
+    payload = np.random.RandomState(20261003 + seed).randint(0, 2, F * D * p.C * mu)
+    np.random.seed(seed)
+    fill = np.random.choice(np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2),
+                            size=(K - p.C), replace=True)       # what random_qpsk will draw
+    np.random.seed(seed)
+    s = quiet(tx.transmit, payload)
+    if gaps is None:
+        gaps = np.random.RandomState(9).randint(0, 300, F)
+    r = split_insert_gaps(s, p, gaps, lead, tail)
+    if channel is not None:
+        from scipy.signal import lfilter
+        r = lfilter(channel, 1.0, r)
+    if drift is not None:
+        r = drift_awgn(r, *drift)
+    out = ref_stages(OFDM, rx, r)
+    # the oracle's synthesiser must reproduce the reference stream bit for bit
+    r2 = orc.tx_stream(payload, fill, p, gaps=gaps, lead=lead, tail=tail)
+    if channel is not None:
+        from scipy.signal import lfilter
+        r2 = lfilter(channel, 1.0, r2)
+    if drift is not None:
+        r2 = drift_awgn(r2, *drift)
+    synth_exact = bool(np.array_equal(r, r2))
+    ber = float(np.mean(out["bits"] != payload))
+    print(f"{name}: n={len(r)} peaks={out['peaks']} slope={out['slope']} BER={ber:.3e} "
+          f"synth_exact={synth_exact} maxdiff={np.max(np.abs(r - r2)):.2e}")
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"),
+        r=r, payload=np.packbits(payload.astype(np.uint8)), n_payload=len(payload),
+        fill=fill, gaps=np.asarray(gaps), lead=lead, tail=tail,
+        N=N, CP=CP, P=P, D=D, lo=lo, hi=hi, mu=mu, seed=seed,
+        const_points=pts, const_bits=bits_tbl, known_bits=known[: max(K * mu, 4096)],
+        channel=np.zeros(0) if channel is None else channel,
+        peaks=out["peaks"], eq=out["eq"], Hs=out["Hs"], He=out["He"], slope=out["slope"],
+        bits=np.packbits(out["bits"]), n_bits=len(out["bits"]), ber=ber,
+        Hest0=out["Hest"][0, :, ::64],     # thin slice of the channel model, frame 0
+        X0=out["X"][0, :, 1:65],           # first 64 used bins of every symbol, frame 0
+    )
+    return p
+
+
+def make_fft(OFDM):
+    rs = np.random.RandomState(5)
+    d = {}
+    for N in (1024, 2048, 4096, 8192):
+        x = rs.randn(4, N)
+        d[f"x{N}"] = x
+        d[f"X{N}"] = np.fft.fft(x)        # the call the reference makes (OFDM.py:593)
+    np.savez_compressed(os.path.join(HERE, "g4_fft_mixedN.npz"), **d)
+    print("g4_fft_mixedN done")
+
+
+def make_demap_edges(OFDM):
+    known = orc.load_known_bits(os.path.join(REF, "Handouts", "random_bits.txt"), 4096)
+    d = {}
+    edge = np.array([0, 1j, -1j, 1, -1, complex(np.nan, 0), complex(np.inf, 0),
+                     complex(0, np.nan), complex(-np.inf, 1), 1e-300, -1e-300j,
+                     0.3 + 0.3j, -0.3 + 0.3j, 0.3 - 0.3j, -0.3 - 0.3j], dtype=complex)
+    rs = np.random.RandomState(11)
+    for mu in (2, 4, 6):
+        pts, bt = orc.qpsk_table() if mu == 2 else orc.square_qam_table(mu)
+        rx = OFDM.receiver(mode="A1", encoding="None")
+        rx.mapping_table = {tuple(int(x) for x in b): complex(c) for b, c in zip(bt, pts)}
+        rx.mu = mu
+        noisy = pts[rs.randint(0, len(pts), 2048)] + 0.15 * (rs.randn(2048) + 1j * rs.randn(2048))
+        # exact decision-boundary ties between neighbouring points
+        ties = np.array([(pts[i] + pts[j]) / 2 for i in range(len(pts)) for j in range(i + 1, min(i + 4, len(pts)))])
+        sym = np.concatenate([edge, noisy, ties]).reshape(1, -1)
+        with np.errstate(all="ignore"):
+            bits, hard = rx.demap(sym)
+        d[f"sym{mu}"] = sym[0]
+        d[f"bits{mu}"] = bits[0].astype(np.uint8)
+        d[f"pts{mu}"] = pts
+        d[f"tbl{mu}"] = bt
+    np.savez_compressed(os.path.join(HERE, "g5_demap_edges.npz"), **d)
+    print("g5_demap_edges done")
+
+
+def make_realrec(OFDM):
+    """Known-answer record of the reference's own end-to-end test
+    (Final System Test.ipynb cells 5-8) plus the recording and source bits it
+    runs on (data files the reference's test holds)."""
+    from scipy.io import wavfile
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fs, raw = wavfile.read("received_signals/gr5ch1_signal.wav")
+    r = raw / 1.0                                              # notebook cell 5
+    rx = OFDM.receiver(mode="A2", encoding="XOR")
+    slopes = []
+    real_polyfit = np.polyfit
+
+    def spy(x, y, deg, *a, **k):
+        out = real_polyfit(x, y, deg, *a, **k)
+        slopes.append(out[0])
+        return out
+
+    np.polyfit = spy
+    try:
+        bits, Hs0, He0 = quiet(rx.receive, r)
+    finally:
+        np.polyfit = real_polyfit
+    zeros = rx.chirp_method(r)
+    src = OFDM.load_file("gr5ch1.bmp")
+    ber = np.sum(bits[:len(src)] != src) / len(src)             # notebook cell 8
+    sha = hashlib.sha256(bits.astype(np.uint8).tobytes()).hexdigest()
+    print("g6_realrec: BER", repr(ber), "sha", sha, "peaks", np.flatnonzero(zeros), "slopes", slopes)
+    assert repr(float(ber)) == "0.023375665289067146"
+    np.savez_compressed(
+        os.path.join(HERE, "g6_realrec.npz"),
+        wav_u8=raw.astype(np.uint8), fs=fs,
+        peaks=np.flatnonzero(zeros), slope=np.array(slopes), ber=float(ber),
+        ber_str="0.023375665289067146", sha256_bits=sha,
+        bits=np.packbits(bits.astype(np.uint8)), n_bits=len(bits),
+        src_bits=np.packbits(src.astype(np.uint8)), n_src=len(src),
+        Hs0=Hs0, He0=He0, known_bits=rx.known_sequence.astype(np.uint8),
+    )
+
+
+def main():
+    OFDM = import_reference()
+    which = set(sys.argv[1:]) or {"g1", "g1b", "g2", "g3", "g4", "g5", "g6", "g7", "g8"}
+    h = np.loadtxt(os.path.join(REF, "Handouts", "gr5channel.csv")).reshape(-1)
+    if "g1" in which:
+        make_loopback(OFDM, "g1_n1024_qpsk", 1024, 128, 2, 8, 2, 2, seed=1)
+    if "g1b" in which:
+        # BASELINE config 1: 64 frames, noiseless; only bits are kept (the stream is
+        # re-synthesised by the oracle from the seed; synth_exact pins that)
+        make_config1(OFDM)
+    if "g2" in which:
+        make_loopback(OFDM, "g2_n4096_qpsk", 4096, 512, 2, 2, 2, 2, seed=2)
+    if "g3" in which:
+        make_loopback(OFDM, "g3_n4096_16qam_gr5", 4096, 512, 2, 4, 2, 4, seed=3, channel=h)
+    if "g7" in which:
+        make_loopback(OFDM, "g7_n4096_qpsk_drift", 4096, 512, 2, 4, 2, 2, seed=4,
+                      drift=(1.0e-4, 0.001, 21))
+    if "g8" in which:
+        make_loopback(OFDM, "g8_n4096_qpsk_gr5_drift", 4096, 512, 2, 4, 2, 2, seed=5, channel=h,
+                      drift=(1.0e-5, 1.0e-4, 22))
+    if "g4" in which:
+        make_fft(OFDM)
+    if "g5" in which:
+        make_demap_edges(OFDM)
+    if "g6" in which:
+        make_realrec(OFDM)
+
+
+def make_config1(OFDM):
+    N, CP, P, D, F, mu, seed = 1024, 128, 2, 8, 64, 2, 7
+    pts, bt = orc.qpsk_table()
+    K = N // 2 - 1
+    known = orc.load_known_bits(os.path.join(REF, "Handouts", "random_bits.txt"), 4096)
+    p = orc.RxParams(N=N, CP=CP, P=P, D=D, lo=1, hi=K, const_points=pts, const_bits=bt, known_bits=known)
+    tx = reparam(OFDM.transmitter(mode="A1", encoding="None", no_pilots=P, packet_length=D),
+                 N, CP, P, D, 1, K, pts, bt, known)
+    rx = reparam(OFDM.receiver(mode="A1", encoding="None", no_pilots=P, packet_length=D),
+                 N, CP, P, D, 1, K, pts, bt, known)
+    payload = np.random.RandomState(20261003).randint(0, 2, F * D * p.C * mu)
+    np.random.seed(seed)
+    fill = np.random.choice(np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2), size=(K - p.C), replace=True)
+    np.random.seed(seed)
+    s = quiet(tx.transmit, payload)
+    gaps = np.random.RandomState(9).randint(0, 300, F)
+    r = split_insert_gaps(s, p, gaps, 64, 64)
+    bits, Hs0, He0 = quiet(rx.receive, r)
+    r2 = orc.tx_stream(payload, fill, p, gaps=gaps, lead=64, tail=64)
+    print("g1b_config1: n=%d BER=%g synth_exact=%s" % (len(r), np.mean(bits != payload), np.array_equal(r, r2)))
+    np.savez_compressed(
+        os.path.join(HERE, "g1b_config1_64f.npz"),
+        N=N, CP=CP, P=P, D=D, F=F, mu=mu, seed=seed, lo=1, hi=K, fill=fill, gaps=gaps, lead=64, tail=64,
+        known_bits=known, n=len(r), r_sha256=hashlib.sha256(r.tobytes()).hexdigest(),
+        bits=np.packbits(bits.astype(np.uint8)), n_bits=len(bits),
+        payload_sha256=hashlib.sha256(payload.astype(np.uint8).tobytes()).hexdigest(),
+        Hs0=Hs0, He0=He0)
+
+
+if __name__ == "__main__":
+    main()
