@@ -1,0 +1,876 @@
+// libgf3rx -- MI355X (gfx950) OFDM receive-path engine: kernels + C ABI.
+// See include/gf3rx.h for the boundary and DESIGN.md for the layout.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "gf3rx.h"
+#include "gf3rx_device.h"
+
+// ============================================================================
+// kernel argument blocks
+// ============================================================================
+struct FftTables {
+    const cplx* tw;    // [NC]      exp(-2 pi i m / NC)
+    const cplx* twn;   // [NC/2+1]  exp(-2 pi i k / N)
+};
+
+struct RfftArgs {
+    FftTables t;
+    const void* in; int64_t n_in; const int64_t* off; int dt;
+    cplx* out;
+};
+
+struct DemodArgs {
+    FftTables t;
+    const void* in; int64_t n_in; const int64_t* off; int dt;
+    int CP, S, P, D, K, C, mu, M;
+    const cplx* known;        // [K]
+    const int* pos;           // [K] data-carrier position or -1
+    const double* cre; const double* cim; const int* clab;   // [M]
+    int fit_lo, fit_hi;       // effective python-slice bounds, fit_hi <= K
+    double xbar, inv_sxx;
+    uint8_t* bits; int row_bytes;
+    cplx* eq; cplx* Hs; cplx* He; double* slope; cplx* Hest; int* status;
+    // spectra mode (receiver.equalise as a stand-alone stage): frequency-domain inputs
+    const cplx* sp_data;      // [F, D, K]
+    const cplx* sp_start;     // [F, P, K]
+    const cplx* sp_end;       // [F, P, K]
+    cplx* eq_all;             // [F*D, K] equalised symbols on all carriers
+};
+
+struct CorrArgs {
+    FftTables t;
+    const void* in; int64_t n_in; int dt;
+    const cplx* Hq;           // [Q][NC+1] spectra of the zero-padded chirp partitions
+    int Q, Lp, Lc, Wmax;
+    // frames mode
+    int64_t stride; int win_lo; int W;
+    int64_t* starts; double* peak; double thresh;
+    // stream mode (starts == nullptr): block b resolves P[b*V .. b*V+V)
+    int V; int64_t plen; double* corr;
+};
+
+// ============================================================================
+// standalone batched real FFT  (remove_cp + np.fft.fft, OFDM.py:407-408,593)
+// ============================================================================
+template <int NC>
+__global__ __launch_bounds__(NC / 8) void rfft_kernel(RfftArgs a) {
+    extern __shared__ double2 smem[];
+    constexpr int T = NC / 8;
+    const int tid = threadIdx.x;
+    const int64_t sym = blockIdx.x;
+    const int64_t off = a.off[sym];
+    cplx* out = a.out + sym * (int64_t)(NC + 1);
+    PairMap<NC> pm;
+    pm.init(tid, a.t.twn);
+    cplx v[8];
+    const bool ok = off >= 0 && off + 2 * NC <= a.n_in;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        v[r] = ok ? load_pair(a.in, off + 2 * (int64_t)(tid + r * T), a.dt) : cmk(0.0, 0.0);
+    fft_core<NC>(v, smem, a.t.tw, tid);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        cplx Xk, Xm;
+        pm.split(smem, m, Xk, Xm);
+        out[pm.k[m]] = Xk;
+        if (!(tid == 0 && m == 0)) out[NC - pm.k[m]] = Xm;
+    }
+    if (tid == 0) {
+        const cplx z0 = smem[0];
+        out[0] = cmk(z0.x + z0.y, 0.0);
+        out[NC] = cmk(z0.x - z0.y, 0.0);
+    }
+}
+
+// ============================================================================
+// fused demodulation of one packet per workgroup
+// (get_symbols..PS, OFDM.py:391-505; equalise :422-480 is the bulk)
+// ============================================================================
+template <int NC, bool SPECTRA>
+__global__ __launch_bounds__(NC / 8) void demod_kernel(DemodArgs a) {
+    extern __shared__ double2 smem[];
+    constexpr int T = NC / 8;
+    cplx* lds = smem;
+    double* scratch = (double*)(smem + FftGeom<NC>::LDS_ELEMS);           // 32 doubles
+    uint32_t* bitbuf = (uint32_t*)(scratch + 32);
+    const int tid = threadIdx.x;
+    const int64_t f = blockIdx.x;
+    const int K = a.K, P = a.P, D = a.D, S = a.S;
+    const int Bs = a.C * a.mu;                                            // bits per data symbol
+    const int nwords = (Bs + 31) / 32 + 2;
+    uint8_t* row = a.bits + f * (int64_t)a.row_bytes;
+
+    int64_t off = 0;
+    if constexpr (!SPECTRA) {
+        off = a.off[f];
+        const bool ok = off >= 0 && off + (int64_t)(2 * P + D) * S <= a.n_in;
+        if (!ok) {                                                        // ragged packet
+            for (int i = tid; i < a.row_bytes; i += T) row[i] = 0;
+            if (tid == 0 && a.status) atomicOr(a.status, 1);
+            return;
+        }
+    }
+
+    PairMap<NC> pm;
+    pm.init(tid, a.t.twn);
+    int bin[8];
+    bool valid[8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        bin[2 * m] = pm.k[m];
+        bin[2 * m + 1] = NC - pm.k[m];
+        valid[2 * m] = true;
+        valid[2 * m + 1] = !(tid == 0 && m == 0);
+    }
+
+    cplx v[8];
+    // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451)
+    cplx Hs[8], He[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) Hs[s] = He[s] = cmk(0.0, 0.0);
+    for (int side = 0; side < 2; ++side) {
+        for (int p = 0; p < P; ++p) {
+            const int symi = side ? (P + D + p) : p;
+            const cplx* sp = nullptr;
+            if constexpr (SPECTRA) {
+                sp = (side ? a.sp_end : a.sp_start) + ((int64_t)f * P + p) * K;
+            } else {
+                const int64_t s0 = off + (int64_t)symi * S + a.CP;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = load_pair(a.in, s0 + 2 * (int64_t)(tid + r * T), a.dt);
+                fft_core<NC>(v, lds, a.t.tw, tid);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                cplx Xk, Xm;
+                if constexpr (SPECTRA) { Xk = sp[bin[2 * m] - 1]; Xm = sp[bin[2 * m + 1] - 1]; }
+                else pm.split(lds, m, Xk, Xm);
+                if (side) { He[2 * m] = cadd(He[2 * m], Xk); He[2 * m + 1] = cadd(He[2 * m + 1], Xm); }
+                else      { Hs[2 * m] = cadd(Hs[2 * m], Xk); Hs[2 * m + 1] = cadd(Hs[2 * m + 1], Xm); }
+            }
+        }
+    }
+    const double dP = (double)P;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const cplx kn = a.known[bin[s] - 1];
+        Hs[s] = cdiv_np(cmk(Hs[s].x / dP, Hs[s].y / dP), kn);
+        He[s] = cdiv_np(cmk(He[s].x / dP, He[s].y / dP), kn);
+        if (valid[s]) {
+            if (a.Hs) a.Hs[f * K + bin[s] - 1] = Hs[s];
+            if (a.He) a.He[f * K + bin[s] - 1] = He[s];
+        }
+    }
+
+    // ---- phase slope: unwrap(angle(He)) - unwrap(angle(Hs)), LS fit (OFDM.py:454-462)
+    double th0[8];
+    __syncthreads();                                  // all reads of Z done; reuse the buffer
+    double* ph0 = (double*)lds;
+    double* ph1 = ph0 + NC;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        th0[s] = atan2(Hs[s].y, Hs[s].x);
+        if (valid[s]) { ph0[bin[s] - 1] = th0[s]; ph1[bin[s] - 1] = atan2(He[s].y, He[s].x); }
+    }
+    __syncthreads();
+    double slope;
+    {
+        const int n0 = tid * 8;
+        double c0[8], c1[8], r0 = 0.0, r1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = n0 + i;
+            if (n >= 1 && n < K) {
+                r0 += unwrap_corr(ph0[n] - ph0[n - 1]);
+                r1 += unwrap_corr(ph1[n] - ph1[n - 1]);
+            }
+            c0[i] = r0; c1[i] = r1;
+        }
+        double e0, e1;
+        block_excl_scan2(r0, r1, scratch, e0, e1);
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = n0 + i;
+            if (n >= a.fit_lo && n < a.fit_hi) {
+                const double y = (ph1[n] + (e1 + c1[i])) - (ph0[n] + (e0 + c0[i]));
+                acc += y * ((double)(n - a.fit_lo) - a.xbar);
+            }
+        }
+        slope = block_sum(acc, scratch + 16) * a.inv_sxx;
+    }
+    if (tid == 0 && a.slope) a.slope[f] = slope;
+
+    // ---- per-carrier equaliser state in registers
+    double a0[8], da[8];
+    int pos[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        a0[s] = hypot(Hs[s].x, Hs[s].y);
+        da[s] = hypot(He[s].x, He[s].y) - a0[s];
+        pos[s] = valid[s] ? a.pos[bin[s] - 1] : -1;
+    }
+    for (int i = tid; i < nwords; i += T) bitbuf[i] = 0;
+    // (fft_core's first barrier also orders this zeroing before the atomics)
+
+    // ---- data symbols: FFT -> /Hest -> demap -> bit-pack (OFDM.py:466-478, 487-505)
+    const double denom = (double)(D + P);
+    for (int l = 0; l < D; ++l) {
+        const cplx* sp = nullptr;
+        if constexpr (SPECTRA) {
+            sp = a.sp_data + ((int64_t)f * D + l) * K;
+            __syncthreads();
+        } else {
+            const int64_t s0 = off + (int64_t)(P + l) * S + a.CP;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = load_pair(a.in, s0 + 2 * (int64_t)(tid + r * T), a.dt);
+            fft_core<NC>(v, lds, a.t.tw, tid);
+        }
+        const double lf = (double)l + 0.5 * (double)P;
+        const int w0 = (l * Bs) >> 5;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            cplx X[2];
+            if constexpr (SPECTRA) { X[0] = sp[bin[2 * m] - 1]; X[1] = sp[bin[2 * m + 1] - 1]; }
+            else pm.split(lds, m, X[0], X[1]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int s = 2 * m + h;
+                const int n = bin[s] - 1;
+                const double mag = a0[s] + da[s] * lf / denom;
+                const double phase = slope * (double)n * lf / denom;
+                double sn, cs;
+                sincos(th0[s] + phase, &sn, &cs);
+                const cplx Hh = cmk(mag * cs, mag * sn);
+                const cplx e = cdiv_np(X[h], Hh);
+                if (valid[s] && a.Hest) a.Hest[((int64_t)f * D + l) * K + n] = Hh;
+                if (valid[s] && a.eq_all) a.eq_all[((int64_t)f * D + l) * K + n] = e;
+                if (pos[s] >= 0) {
+                    if (a.eq) a.eq[((int64_t)f * D + l) * a.C + pos[s]] = e;
+                    int best = 0;
+                    double dx = e.x - a.cre[0], dy = e.y - a.cim[0];
+                    double bd = dx * dx + dy * dy;
+                    for (int c = 1; c < a.M; ++c) {
+                        dx = e.x - a.cre[c]; dy = e.y - a.cim[c];
+                        const double d = dx * dx + dy * dy;
+                        if (d < bd) { bd = d; best = c; }
+                    }
+                    const uint32_t lab = (uint32_t)a.clab[best];
+                    const int o = (l * a.C + pos[s]) * a.mu;
+                    const uint64_t val = (uint64_t)lab << (64 - a.mu - (o & 31));
+                    const int w = (o >> 5) - w0;
+                    atomicOr(&bitbuf[w], (uint32_t)(val >> 32));
+                    if ((uint32_t)val) atomicOr(&bitbuf[w + 1], (uint32_t)val);
+                }
+            }
+        }
+        __syncthreads();
+        // flush the words this symbol completed; carry the partial one
+        const int w1 = ((l + 1) * Bs) >> 5;
+        const bool last = (l == D - 1);
+        for (int w = w0 + tid; w < w1; w += T) {
+            const uint32_t x = bitbuf[w - w0];
+            if ((a.row_bytes & 3) == 0) ((uint32_t*)row)[w] = __builtin_bswap32(x);
+            else { row[4 * w] = x >> 24; row[4 * w + 1] = x >> 16; row[4 * w + 2] = x >> 8; row[4 * w + 3] = x; }
+        }
+        uint32_t carry = 0;
+        if (tid == 0) {
+            const int rem = ((l + 1) * Bs) & 31;
+            if (rem) carry = bitbuf[w1 - w0];
+            if (last && rem) {
+                const int nb = (rem + 7) >> 3;
+                for (int b = 0; b < nb; ++b) row[4 * w1 + b] = (uint8_t)(carry >> (24 - 8 * b));
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nwords; i += T) bitbuf[i] = (i == 0) ? carry : 0u;
+    }
+}
+
+// ============================================================================
+// chirp matched filter by partitioned FFT correlation
+// (convolve(r, chirp[::-1]) + peak rule, OFDM.py:357-361)
+//   corr[s] = sum_k r[s+k] c[k],  s = s0 .. s0+W-1   (== P[s+Lc-1])
+//   c split into Q partitions of Lp taps; each partition's contribution is a
+//   circular correlation of size N = 2NC, valid for lags < N-Lp+1.
+// ============================================================================
+template <int NC>
+__global__ __launch_bounds__(NC / 8) void corr_kernel(CorrArgs a) {
+    extern __shared__ double2 smem[];
+    constexpr int T = NC / 8;
+    cplx* lds = smem;
+    double* scratch = (double*)(smem + FftGeom<NC>::LDS_ELEMS);
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const bool frames = a.starts != nullptr;
+    int64_t s0;                  // absolute sample index of lag 0 of this block
+    int W;                       // lags this block must resolve
+    if (frames) { s0 = b * a.stride + a.win_lo; W = a.W; }
+    else {
+        const int64_t m0 = b * (int64_t)a.V;
+        s0 = m0 - (a.Lc - 1);
+        const int64_t left = a.plen - m0;
+        W = left < a.V ? (int)left : a.V;
+    }
+
+    PairMap<NC> pm;
+    pm.init(tid, a.t.twn);
+    cplx acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = cmk(0.0, 0.0);
+    double accDC = 0.0, accNy = 0.0;
+    const int need = a.Lp + a.Wmax - 1;           // samples of a segment that reach valid lags
+    cplx v[8];
+    for (int q = 0; q < a.Q; ++q) {
+        const int64_t seg = s0 + (int64_t)q * a.Lp;
+        const cplx* Hq = a.Hq + (int64_t)q * (NC + 1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int j = 2 * (tid + r * T);
+            const double x0 = (j < need) ? load_sample_clamped(a.in, seg + j, a.n_in, a.dt) : 0.0;
+            const double x1 = (j + 1 < need) ? load_sample_clamped(a.in, seg + j + 1, a.n_in, a.dt) : 0.0;
+            v[r] = cmk(x0, x1);
+        }
+        fft_core<NC>(v, lds, a.t.tw, tid);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            cplx Xk, Xm;
+            pm.split(lds, m, Xk, Xm);
+            acc[2 * m] = cadd(acc[2 * m], cmul_conj(Xk, Hq[pm.k[m]]));
+            acc[2 * m + 1] = cadd(acc[2 * m + 1], cmul_conj(Xm, Hq[NC - pm.k[m]]));
+        }
+        if (tid == 0) {
+            const cplx z0 = lds[0];
+            accDC += (z0.x + z0.y) * Hq[0].x;
+            accNy += (z0.x - z0.y) * Hq[NC].x;
+        }
+    }
+    // ---- inverse real FFT of the accumulated Hermitian spectrum Y
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const cplx A = acc[2 * m];
+        const cplx B = cconj(acc[2 * m + 1]);
+        const cplx E = cscale(cadd(A, B), 0.5);
+        const cplx Op = cmul_conj(cscale(csub(A, B), 0.5), pm.w[m]);       // * exp(+2 pi i k/N)
+        const cplx Zk = cadd(E, mul_posi(Op));
+        const cplx Zm = cadd(cconj(E), mul_posi(cconj(Op)));
+        lds[pm.k[m]] = cconj(Zk);
+        if (!(tid == 0 && m == 0)) lds[NC - pm.k[m]] = cconj(Zm);
+    }
+    if (tid == 0) {
+        const double E = 0.5 * (accDC + accNy), Op = 0.5 * (accDC - accNy);
+        lds[0] = cmk(E, -Op);                                               // conj(E + i Op)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = lds[tid + r * T];
+    fft_core<NC>(v, lds, a.t.tw, tid);
+    // z = conj(FFT(conj Z))/NC ; y[2n] = Re z, y[2n+1] = Im z  -> in place as doubles
+    const double inv = 1.0 / (double)NC;
+    for (int i = tid; i < NC; i += T) { const cplx z = lds[i]; lds[i] = cmk(z.x * inv, -z.y * inv); }
+    __syncthreads();
+    const double* y = (const double*)lds;
+
+    if (!frames) {
+        const int64_t m0 = b * (int64_t)a.V;
+        for (int j = tid; j < W; j += T) a.corr[m0 + j] = y[j];
+        return;
+    }
+    // ---- peak rule on the window (OFDM.py:359-361): normalise by the max, first
+    // local extremum above thresh
+    double mx = -INFINITY;
+    for (int j = tid; j < W; j += T) mx = fmax(mx, y[j]);
+    mx = block_max(mx, scratch);
+    int first = 0x7fffffff;
+    for (int j = 1 + tid; j < W - 1; j += T) {
+        const double pm1 = y[j - 1] / mx, p0 = y[j] / mx, pp1 = y[j + 1] / mx;
+        if (((p0 - pm1) * (pp1 - p0) <= 0.0) && (p0 > a.thresh)) first = min(first, j);
+    }
+    first = block_min_i(first, (int*)(scratch + 16));
+    if (tid == 0) {
+        const bool found = first != 0x7fffffff;
+        a.starts[b] = found ? (s0 + first + a.Lc) : -1;
+        if (a.peak) a.peak[b] = found ? y[first] : 0.0;
+    }
+}
+
+// ============================================================================
+// stream-mode peak picking on the full correlation P (OFDM.py:359-370)
+// ============================================================================
+#define PK_THREADS 256
+#define PK_ITEMS 8
+
+__global__ void pk_max_partial(const double* __restrict__ P, int64_t len, double* partial) {
+    __shared__ double scratch[16];
+    double mx = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x)
+        mx = fmax(mx, P[i]);
+    mx = block_max(mx, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = mx;
+}
+__global__ void pk_max_final(const double* partial, int n, double* out) {
+    __shared__ double scratch[16];
+    double mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmax(mx, partial[i]);
+    mx = block_max(mx, scratch);
+    if (threadIdx.x == 0) out[0] = mx;
+}
+GF3_DEV bool pk_is_cand(const double* __restrict__ P, int64_t i, double mx, double thresh) {
+    const double p0 = P[i] / mx, p1 = P[i + 1] / mx, p2 = P[i + 2] / mx;
+    return ((p1 - p0) * (p2 - p1) <= 0.0) && (p1 > thresh);
+}
+// pass 0: count per block; pass 1: write ascending indices at the block's offset
+__global__ void pk_candidates(const double* __restrict__ P, int64_t nz, const double* mxp, double thresh,
+                              int64_t* counts, const int64_t* offsets, int64_t* cand) {
+    __shared__ int wsum[PK_THREADS / 64];
+    const double mx = mxp[0];
+    const int64_t base = ((int64_t)blockIdx.x * PK_THREADS + threadIdx.x) * PK_ITEMS;
+    int c = 0;
+    unsigned flags = 0;
+    for (int k = 0; k < PK_ITEMS; ++k) {
+        const int64_t i = base + k;
+        if (i < nz && pk_is_cand(P, i, mx, thresh)) { flags |= 1u << k; ++c; }
+    }
+    // block-wide exclusive scan of c
+    int x = c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < PK_THREADS / 64; ++w) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+    if (!offsets) { if (threadIdx.x == 0) counts[blockIdx.x] = total; return; }
+    int64_t o = offsets[blockIdx.x] + woff + (x - c);
+    for (int k = 0; k < PK_ITEMS; ++k) if (flags & (1u << k)) cand[o++] = base + k;
+}
+__global__ void pk_scan(const int64_t* counts, int64_t n, int64_t* offsets, int64_t* total) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int64_t base = 0; base < n; base += blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t c = i < n ? counts[i] : 0;
+        int64_t x = c;
+        for (int d = 1; d < 64; d <<= 1) { const int64_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int64_t woff = 0, tot = 0;
+        for (int w = 0; w < nw; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+        if (i < n) offsets[i] = carry + woff + (x - c);
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+}
+// sequential suppression (OFDM.py:364-370) over the sorted candidate list
+__global__ void pk_nms(const int64_t* cand, const int64_t* totalp, int64_t Lc, int64_t nz,
+                       int64_t* peaks, int64_t cap, int64_t* npeaks) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t total = totalp[0];
+    int64_t pos = 0, np = 0;
+    int64_t status = 0;
+    while (pos < total) {
+        const int64_t i = cand[pos];
+        if (i + Lc >= nz) { np = 0; status = 1; break; }          // the except-branch wipes everything
+        if (np < cap) peaks[np] = i; else status = 2;
+        ++np;
+        const int64_t want = i + Lc + 1;                            // first candidate past the cleared run
+        int64_t lo = pos + 1, hi = total;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cand[mid] < want) lo = mid + 1; else hi = mid; }
+        pos = lo;
+    }
+    npeaks[0] = np;
+    npeaks[1] = status;
+}
+
+// ============================================================================
+// standalone demappers
+// ============================================================================
+struct DemapArgs {
+    const cplx* sym; int64_t n; int M, mu;
+    const double* cre; const double* cim; const int* clab;
+    uint8_t* bits; float* llr; double inv_nv; uint8_t* idx;
+};
+__global__ void demap_hard_kernel(DemapArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cplx e = a.sym[i];
+        int best = 0;
+        double dx = e.x - a.cre[0], dy = e.y - a.cim[0];
+        double bd = dx * dx + dy * dy;
+        for (int c = 1; c < a.M; ++c) {
+            dx = e.x - a.cre[c]; dy = e.y - a.cim[c];
+            const double d = dx * dx + dy * dy;
+            if (d < bd) { bd = d; best = c; }
+        }
+        const int lab = a.clab[best];
+        for (int b = 0; b < a.mu; ++b) a.bits[i * a.mu + b] = (lab >> (a.mu - 1 - b)) & 1;
+        if (a.idx) a.idx[i] = (uint8_t)best;
+    }
+}
+__global__ void soft_demap_kernel(DemapArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cplx e = a.sym[i];
+        double m0[8], m1[8];
+        for (int b = 0; b < 8; ++b) m0[b] = m1[b] = INFINITY;
+        for (int c = 0; c < a.M; ++c) {
+            const double dx = e.x - a.cre[c], dy = e.y - a.cim[c];
+            const double d = dx * dx + dy * dy;
+            const int lab = a.clab[c];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (b < a.mu) {
+                    if ((lab >> (a.mu - 1 - b)) & 1) m1[b] = fmin(m1[b], d); else m0[b] = fmin(m0[b], d);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            if (b < a.mu) a.llr[i * a.mu + b] = (float)((m1[b] - m0[b]) * a.inv_nv);
+    }
+}
+
+// ============================================================================
+// host side: context + C ABI
+// ============================================================================
+struct CorrPlan { int Q = 0, Lp = 0, W = 0; cplx* d_Hq = nullptr; };
+
+struct gf3_ctx {
+    gf3_config cfg;
+    int NC, K, S, Lc, row_bytes;
+    int fit_lo, fit_hi;
+    double xbar, inv_sxx;
+    cplx *d_tw = nullptr, *d_twn = nullptr, *d_known = nullptr;
+    int *d_pos = nullptr, *d_clab = nullptr;
+    double *d_cre = nullptr, *d_cim = nullptr;
+    CorrPlan frames_plan, stream_plan;
+    std::vector<double> chirp;
+    mutable char err[512];
+};
+
+static char g_err[512] = "";
+
+static int fail(const gf3_ctx* c, int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    char* dst = c ? c->err : g_err;
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    if (c) memcpy(g_err, c->err, 512);
+    return code;
+}
+#define HIPCHK(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return fail(c, GF3_EHIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
+
+template <typename T> static hipError_t upload(T** dptr, const T* h, size_t n) {
+    hipError_t e = hipMalloc((void**)dptr, n * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice);
+}
+
+static size_t fft_lds_bytes(int NC) { return (size_t)(NC + NC / 8) * sizeof(cplx); }
+
+template <typename Kern, typename Args>
+static hipError_t launch(Kern k, int64_t grid, int threads, size_t lds, hipStream_t st, const Args& a) {
+    if (grid <= 0) return hipSuccess;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(threads), lds, st, a);
+    return hipGetLastError();
+}
+
+#define DISPATCH_NC(NCv, CALL)                                  \
+    switch (NCv) {                                              \
+        case 512:  { constexpr int NCC = 512;  CALL; break; }   \
+        case 1024: { constexpr int NCC = 1024; CALL; break; }   \
+        case 2048: { constexpr int NCC = 2048; CALL; break; }   \
+        default:   { constexpr int NCC = 4096; CALL; break; }   \
+    }
+
+static hipError_t run_rfft(const gf3_ctx* c, const void* d_in, int64_t n_in, int dt, const int64_t* d_off,
+                           int64_t n_sym, cplx* d_out, hipStream_t st) {
+    RfftArgs a{{c->d_tw, c->d_twn}, d_in, n_in, d_off, dt, d_out};
+    hipError_t e = hipSuccess;
+    DISPATCH_NC(c->NC, e = launch(rfft_kernel<NCC>, n_sym, NCC / 8, fft_lds_bytes(NCC), st, a));
+    return e;
+}
+
+// spectra of the zero-padded chirp partitions, computed with the engine's own FFT
+static int build_plan(gf3_ctx* c, CorrPlan* pl, int Lp_max) {
+    const int N = 2 * c->NC;
+    int Q = (c->Lc + Lp_max - 1) / Lp_max;
+    int Lp = (c->Lc + Q - 1) / Q;
+    pl->Q = Q; pl->Lp = Lp; pl->W = N - Lp + 1;
+    std::vector<double> h((size_t)Q * N, 0.0);
+    for (int q = 0; q < Q; ++q)
+        for (int k = 0; k < Lp && q * Lp + k < c->Lc; ++k) h[(size_t)q * N + k] = c->chirp[(size_t)q * Lp + k];
+    std::vector<int64_t> off(Q);
+    for (int q = 0; q < Q; ++q) off[q] = (int64_t)q * N;
+    double* d_h = nullptr; int64_t* d_off = nullptr;
+    HIPCHK(c, upload(&d_h, h.data(), h.size()));
+    HIPCHK(c, upload(&d_off, off.data(), off.size()));
+    HIPCHK(c, hipMalloc((void**)&pl->d_Hq, (size_t)Q * (c->NC + 1) * sizeof(cplx)));
+    HIPCHK(c, run_rfft(c, d_h, (int64_t)h.size(), DT_F64, d_off, Q, pl->d_Hq, 0));
+    HIPCHK(c, hipStreamSynchronize(0));
+    (void)hipFree(d_h); (void)hipFree(d_off);
+    return GF3_OK;
+}
+
+extern "C" const char* gf3_version(void) { return GF3RX_VERSION; }
+
+extern "C" const char* gf3_last_error(const gf3_ctx* ctx) { return ctx ? ctx->err : g_err; }
+
+extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, GF3_EINVAL, "null argument");
+    *out = nullptr;
+    const int N = cfg->N;
+    if (N != 1024 && N != 2048 && N != 4096 && N != 8192)
+        return fail(nullptr, GF3_EINVAL, "N=%d unsupported (1024, 2048, 4096, 8192)", N);
+    if (cfg->CP < 0 || cfg->P < 1 || cfg->D < 1) return fail(nullptr, GF3_EINVAL, "need CP>=0, P>=1, D>=1");
+    if (cfg->M < 2 || cfg->M > 64 || cfg->mu < 1 || cfg->mu > 8 || (1 << cfg->mu) < cfg->M)
+        return fail(nullptr, GF3_EINVAL, "Invalid Modulation Type (M=%d, mu=%d)", cfg->M, cfg->mu);
+    if (!cfg->const_re || !cfg->const_im || !cfg->const_bits || !cfg->known_re || !cfg->known_im || !cfg->data_bins)
+        return fail(nullptr, GF3_EINVAL, "null table pointer");
+    if (cfg->in_dtype < 0 || cfg->in_dtype > 3) return fail(nullptr, GF3_EINVAL, "bad in_dtype");
+    gf3_ctx* c = new gf3_ctx();
+    c->cfg = *cfg;
+    c->err[0] = 0;
+    c->NC = N / 2; c->K = N / 2 - 1; c->S = N + cfg->CP;
+    c->Lc = cfg->Lc > 0 ? cfg->Lc : 5 * c->S;
+    const int K = c->K;
+    if (cfg->C < 1 || cfg->C > K) { delete c; return fail(nullptr, GF3_EINVAL, "C out of range"); }
+    c->row_bytes = (int)(((int64_t)cfg->D * cfg->C * cfg->mu + 7) / 8);
+    // polyfit range: python slice [fit_lo:fit_hi] of a length-K row (OFDM.py:462)
+    c->fit_lo = cfg->fit_lo < K ? cfg->fit_lo : K;
+    c->fit_hi = cfg->fit_hi < K ? cfg->fit_hi : K;
+    const int L = c->fit_hi - c->fit_lo;
+    if (L < 2) { delete c; return fail(nullptr, GF3_EINVAL, "phase-slope fit range [%d:%d] holds %d carriers (K=%d)", cfg->fit_lo, cfg->fit_hi, L, K); }
+    c->xbar = 0.5 * (L - 1);
+    { double sxx = 0; for (int i = 0; i < L; ++i) { const double d = i - c->xbar; sxx += d * d; } c->inv_sxx = 1.0 / sxx; }
+
+    const int NC = c->NC;
+    std::vector<cplx> tw(NC), twn(NC / 2 + 1), known(K);
+    const long double PI2 = 6.283185307179586476925286766559005768L;
+    for (int m = 0; m < NC; ++m) { const long double a = -PI2 * m / NC; tw[m] = make_double2((double)cosl(a), (double)sinl(a)); }
+    for (int k = 0; k <= NC / 2; ++k) { const long double a = -PI2 * k / N; twn[k] = make_double2((double)cosl(a), (double)sinl(a)); }
+    for (int k = 0; k < K; ++k) known[k] = make_double2(cfg->known_re[k], cfg->known_im[k]);
+    std::vector<int> pos(K, -1), clab(cfg->M);
+    for (int i = 0; i < cfg->C; ++i) {
+        const int b = cfg->data_bins[i];
+        if (b < 1 || b > K || pos[b - 1] != -1) { delete c; return fail(nullptr, GF3_EINVAL, "data_bins[%d]=%d invalid or repeated", i, b); }
+        pos[b - 1] = i;
+    }
+    for (int m = 0; m < cfg->M; ++m) {
+        int lab = 0;
+        for (int b = 0; b < cfg->mu; ++b) lab = (lab << 1) | (cfg->const_bits[m * cfg->mu + b] & 1);
+        clab[m] = lab;
+    }
+    // chirp replica (sync_chirp, OFDM.py:106-109): linspace incl. endpoint, scipy linear chirp, /5
+    c->chirp.resize(c->Lc);
+    {
+        const double t1 = (double)c->Lc / cfg->fs;
+        const double step = t1 / (double)(c->Lc - 1);
+        const double beta = (cfg->f1 - cfg->f0) / t1;
+        for (int i = 0; i < c->Lc; ++i) {
+            const double t = (i == c->Lc - 1) ? t1 : (double)i * step;
+            const double ph = 2 * M_PI * (cfg->f0 * t + 0.5 * beta * t * t);
+            c->chirp[i] = cos(ph) / 5;
+        }
+    }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { int rc_ = fail(nullptr, GF3_EHIP, "%s: %s", #x, hipGetErrorString(e_)); gf3_ctx_destroy(c); return rc_; } } while (0)
+    CK(upload(&c->d_tw, tw.data(), tw.size()));
+    CK(upload(&c->d_twn, twn.data(), twn.size()));
+    CK(upload(&c->d_known, known.data(), known.size()));
+    CK(upload(&c->d_pos, pos.data(), pos.size()));
+    CK(upload(&c->d_clab, clab.data(), clab.size()));
+    CK(upload(&c->d_cre, cfg->const_re, (size_t)cfg->M));
+    CK(upload(&c->d_cim, cfg->const_im, (size_t)cfg->M));
+#undef CK
+    // the tables are now device-resident; do not keep the caller's host pointers
+    c->cfg.const_re = c->cfg.const_im = c->cfg.known_re = c->cfg.known_im = nullptr;
+    c->cfg.const_bits = nullptr; c->cfg.data_bins = nullptr;
+    int wmax = cfg->max_window > 0 ? cfg->max_window : 512;
+    if (wmax > N / 2) wmax = N / 2;
+    int rc = build_plan(c, &c->frames_plan, N - wmax + 1);
+    if (rc == GF3_OK) rc = build_plan(c, &c->stream_plan, N / 2);
+    if (rc != GF3_OK) { memcpy(g_err, c->err, 512); gf3_ctx_destroy(c); return rc; }
+    *out = c;
+    return GF3_OK;
+}
+
+extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
+    if (!c) return;
+    void* ptrs[] = {c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
+                    c->frames_plan.d_Hq, c->stream_plan.d_Hq};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete c;
+}
+
+extern "C" int32_t gf3_bytes_per_frame(const gf3_ctx* c) { return c ? c->row_bytes : 0; }
+extern "C" int32_t gf3_sync_max_window(const gf3_ctx* c) { return c ? c->frames_plan.W : 0; }
+
+extern "C" int gf3_chirp_replica(const gf3_ctx* c, double* h_out) {
+    if (!c || !h_out) return fail(c, GF3_EINVAL, "null argument");
+    memcpy(h_out, c->chirp.data(), c->chirp.size() * sizeof(double));
+    return GF3_OK;
+}
+
+extern "C" int gf3_rfft_batch(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_offsets, int64_t n_sym,
+                              void* d_out, void* stream) {
+    if (!c || !d_in || !d_offsets || !d_out || n_sym < 0) return fail(c, GF3_EINVAL, "gf3_rfft_batch: bad argument");
+    HIPCHK(c, run_rfft(c, d_in, n_in, c->cfg.in_dtype, d_offsets, n_sym, (cplx*)d_out, (hipStream_t)stream));
+    return GF3_OK;
+}
+
+static size_t demod_lds_bytes(const gf3_ctx* c) {
+    return fft_lds_bytes(c->NC) + 32 * sizeof(double) + (size_t)((c->cfg.C * c->cfg.mu + 31) / 32 + 2) * 4;
+}
+
+extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,
+                                uint8_t* d_bits, void* d_eq, void* d_Hs, void* d_He, double* d_slope, void* d_Hest,
+                                int32_t* d_status, void* stream) {
+    if (!c || !d_in || !d_off || !d_bits || F < 0) return fail(c, GF3_EINVAL, "gf3_demod_frames: bad argument");
+    const gf3_config& g = c->cfg;
+    DemodArgs a{{c->d_tw, c->d_twn}, d_in, n_in, d_off, g.in_dtype,
+                g.CP, c->S, g.P, g.D, c->K, g.C, g.mu, g.M,
+                c->d_known, c->d_pos, c->d_cre, c->d_cim, c->d_clab,
+                c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
+                d_bits, c->row_bytes, (cplx*)d_eq, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, d_status,
+                nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    DISPATCH_NC(c->NC, e = launch((demod_kernel<NCC, false>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+    HIPCHK(c, e);
+    return GF3_OK;
+}
+
+extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start, const void* d_end, int64_t F,
+                            void* d_eq_all, void* d_Hs, void* d_He, double* d_slope, void* d_Hest,
+                            uint8_t* d_bits, void* stream) {
+    if (!c || !d_data || !d_start || !d_end || !d_bits || F < 0) return fail(c, GF3_EINVAL, "gf3_equalise: bad argument");
+    const gf3_config& g = c->cfg;
+    DemodArgs a{{c->d_tw, c->d_twn}, nullptr, 0, nullptr, g.in_dtype,
+                g.CP, c->S, g.P, g.D, c->K, g.C, g.mu, g.M,
+                c->d_known, c->d_pos, c->d_cre, c->d_cim, c->d_clab,
+                c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
+                d_bits, c->row_bytes, nullptr, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, nullptr,
+                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all};
+    hipError_t e = hipSuccess;
+    DISPATCH_NC(c->NC, e = launch((demod_kernel<NCC, true>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+    HIPCHK(c, e);
+    return GF3_OK;
+}
+
+static hipError_t run_corr(const gf3_ctx* c, const CorrArgs& a, int64_t grid, hipStream_t st) {
+    const size_t lds = fft_lds_bytes(c->NC) + 32 * sizeof(double);
+    hipError_t e = hipSuccess;
+    DISPATCH_NC(c->NC, e = launch(corr_kernel<NCC>, grid, NCC / 8, lds, st, a));
+    return e;
+}
+
+extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64_t F, int64_t stride,
+                               int32_t win_lo, int32_t win_hi, int64_t* d_starts, double* d_peak, void* stream) {
+    if (!c || !d_in || !d_starts || F < 0) return fail(c, GF3_EINVAL, "gf3_sync_frames: bad argument");
+    const int W = win_hi - win_lo;
+    const CorrPlan& pl = c->frames_plan;
+    if (W < 3 || W > pl.W) return fail(c, GF3_EINVAL, "gf3_sync_frames: window %d outside [3, %d]", W, pl.W);
+    CorrArgs a{};
+    a.t = {c->d_tw, c->d_twn}; a.in = d_in; a.n_in = n_in; a.dt = c->cfg.in_dtype;
+    a.Hq = pl.d_Hq; a.Q = pl.Q; a.Lp = pl.Lp; a.Lc = c->Lc; a.Wmax = W;
+    a.stride = stride; a.win_lo = win_lo; a.W = W; a.starts = d_starts; a.peak = d_peak; a.thresh = c->cfg.thresh;
+    HIPCHK(c, run_corr(c, a, F, (hipStream_t)stream));
+    return GF3_OK;
+}
+
+// workspace layout for gf3_sync_stream
+struct StreamWs { int64_t plen, nz, nb_max, nb_c; size_t o_P, o_part, o_cnt, o_off, o_cand, o_misc, total; };
+static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
+    StreamWs w;
+    w.plen = n + c->Lc - 1; w.nz = w.plen - 2;
+    w.nb_max = 1024;
+    w.nb_c = (w.nz + PK_THREADS * PK_ITEMS - 1) / (PK_THREADS * PK_ITEMS);
+    if (w.nb_c < 1) w.nb_c = 1;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 255) & ~(size_t)255; return r; };
+    w.o_P = take((size_t)w.plen * 8);
+    w.o_part = take((size_t)w.nb_max * 8);
+    w.o_cnt = take((size_t)w.nb_c * 8);
+    w.o_off = take((size_t)w.nb_c * 8);
+    w.o_cand = take((size_t)(w.nz / 2 + 2) * 8);
+    w.o_misc = take(64);
+    w.total = o;
+    return w;
+}
+extern "C" int64_t gf3_sync_stream_workspace_bytes(const gf3_ctx* c, int64_t n) {
+    if (!c || n < 1) return 0;
+    return (int64_t)stream_ws(c, n).total;
+}
+
+extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* d_peaks, int64_t cap,
+                               int64_t* n_peaks, void* d_work, double* d_corr, void* stream) {
+    if (!c || !d_r || !d_peaks || !n_peaks || !d_work || n < 3 || cap < 1)
+        return fail(c, GF3_EINVAL, "gf3_sync_stream: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const StreamWs w = stream_ws(c, n);
+    char* base = (char*)d_work;
+    double* P = d_corr ? d_corr : (double*)(base + w.o_P);
+    double* part = (double*)(base + w.o_part);
+    int64_t* cnt = (int64_t*)(base + w.o_cnt);
+    int64_t* offs = (int64_t*)(base + w.o_off);
+    int64_t* cand = (int64_t*)(base + w.o_cand);
+    double* mx = (double*)(base + w.o_misc);
+    int64_t* total = (int64_t*)(base + w.o_misc + 8);
+    int64_t* np = (int64_t*)(base + w.o_misc + 16);        // [count, status]
+    const CorrPlan& pl = c->stream_plan;
+    CorrArgs a{};
+    a.t = {c->d_tw, c->d_twn}; a.in = d_r; a.n_in = n; a.dt = c->cfg.in_dtype;
+    a.Hq = pl.d_Hq; a.Q = pl.Q; a.Lp = pl.Lp; a.Lc = c->Lc; a.Wmax = pl.W;
+    a.starts = nullptr; a.V = pl.W; a.plen = w.plen; a.corr = P;
+    const int64_t nblk = (w.plen + pl.W - 1) / pl.W;
+    HIPCHK(c, run_corr(c, a, nblk, st));
+    hipLaunchKernelGGL(pk_max_partial, dim3((unsigned)w.nb_max), dim3(256), 0, st, (const double*)P, w.plen, part);
+    hipLaunchKernelGGL(pk_max_final, dim3(1), dim3(256), 0, st, (const double*)part, (int)w.nb_max, mx);
+    hipLaunchKernelGGL(pk_candidates, dim3((unsigned)w.nb_c), dim3(PK_THREADS), 0, st, (const double*)P, w.nz,
+                       (const double*)mx, c->cfg.thresh, cnt, (const int64_t*)nullptr, (int64_t*)nullptr);
+    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.nb_c, offs, total);
+    hipLaunchKernelGGL(pk_candidates, dim3((unsigned)w.nb_c), dim3(PK_THREADS), 0, st, (const double*)P, w.nz,
+                       (const double*)mx, c->cfg.thresh, cnt, (const int64_t*)offs, cand);
+    hipLaunchKernelGGL(pk_nms, dim3(1), dim3(64), 0, st, (const int64_t*)cand, (const int64_t*)total,
+                       (int64_t)c->Lc, w.nz, d_peaks, cap, np);
+    HIPCHK(c, hipGetLastError());
+    int64_t h[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, np, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *n_peaks = h[0];
+    if (h[1] == 2) return fail(c, GF3_ERANGE, "gf3_sync_stream: %lld peaks exceed capacity %lld", (long long)h[0], (long long)cap);
+    return GF3_OK;
+}
+
+static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, uint8_t* idx, float* llr, double nv, void* stream) {
+    DemapArgs a{(const cplx*)d_sym, n, c->cfg.M, c->cfg.mu, c->d_cre, c->d_cim, c->d_clab, bits, llr, nv > 0 ? 1.0 / nv : 0.0, idx};
+    int64_t grid = (n + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (grid < 1) return GF3_OK;
+    if (bits) hipLaunchKernelGGL(demap_hard_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(soft_demap_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    HIPCHK(c, hipGetLastError());
+    return GF3_OK;
+}
+extern "C" int gf3_demap_hard(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* d_bits, uint8_t* d_idx, void* stream) {
+    if (!c || !d_sym || !d_bits || n < 0) return fail(c, GF3_EINVAL, "gf3_demap_hard: bad argument");
+    return run_demap(c, d_sym, n, d_bits, d_idx, nullptr, 1.0, stream);
+}
+extern "C" int gf3_soft_demap(gf3_ctx* c, const void* d_sym, int64_t n, double noise_var, float* d_llr, void* stream) {
+    if (!c || !d_sym || !d_llr || n < 0 || !(noise_var > 0)) return fail(c, GF3_EINVAL, "gf3_soft_demap: bad argument");
+    return run_demap(c, d_sym, n, nullptr, nullptr, d_llr, noise_var, stream);
+}

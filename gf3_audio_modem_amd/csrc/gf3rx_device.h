@@ -1,0 +1,262 @@
+// Device-side building blocks of libgf3rx (gfx950 / CDNA4, wave64).
+//
+// Everything computes in fp64 (SURVEY.md §7 "Precision": fp32 fails both the
+// bit-exact and the 1e-6 symbol bar on real recordings).  Samples are stored as
+// f64/f32/i16/u8 and widened in registers.
+//
+// FFT: a length-N real symbol is packed as NC = N/2 complex points
+// z[n] = x[2n] + i x[2n+1]; NC/8 threads each own 8 points and run Stockham
+// autosort passes (radix 8 with a radix-4 tail) through one in-place LDS buffer;
+// the packed-real split is then done on (k, NC-k) pairs held by ONE thread, so
+// the per-carrier equaliser state lives in that thread's registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef double2 cplx;
+
+#define GF3_DEV __device__ __forceinline__
+
+GF3_DEV cplx cmk(double a, double b) { return make_double2(a, b); }
+GF3_DEV cplx cadd(cplx a, cplx b) { return cmk(a.x + b.x, a.y + b.y); }
+GF3_DEV cplx csub(cplx a, cplx b) { return cmk(a.x - b.x, a.y - b.y); }
+GF3_DEV cplx cconj(cplx a) { return cmk(a.x, -a.y); }
+GF3_DEV cplx cscale(cplx a, double s) { return cmk(a.x * s, a.y * s); }
+GF3_DEV cplx cmul(cplx a, cplx b) { return cmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+GF3_DEV cplx cmul_conj(cplx a, cplx b) { return cmk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
+GF3_DEV cplx mul_negi(cplx a) { return cmk(a.y, -a.x); }   // a * (-i)
+GF3_DEV cplx mul_posi(cplx a) { return cmk(-a.y, a.x); }   // a * (+i)
+
+// complex division the way NumPy does it for complex128 (Smith's method)
+GF3_DEV cplx cdiv_np(cplx a, cplx b) {
+    const double br = fabs(b.x), bi = fabs(b.y);
+    if (br >= bi) {
+        if (br == 0.0 && bi == 0.0) return cmk(a.x / br, a.y / bi);
+        const double rat = b.y / b.x;
+        const double scl = 1.0 / (b.x + b.y * rat);
+        return cmk((a.x + a.y * rat) * scl, (a.y - a.x * rat) * scl);
+    }
+    const double rat = b.x / b.y;
+    const double scl = 1.0 / (b.y + b.x * rat);
+    return cmk((a.x * rat + a.y) * scl, (a.y * rat - a.x) * scl);
+}
+
+enum { DT_F64 = 0, DT_F32 = 1, DT_I16 = 2, DT_U8 = 3 };
+
+GF3_DEV double load_sample(const void* p, int64_t i, int dt) {
+    switch (dt) {
+        case DT_F64: return ((const double*)p)[i];
+        case DT_F32: return (double)((const float*)p)[i];
+        case DT_I16: return (double)((const int16_t*)p)[i];
+        default:     return (double)((const uint8_t*)p)[i];
+    }
+}
+GF3_DEV cplx load_pair(const void* p, int64_t i, int dt) {
+    return cmk(load_sample(p, i, dt), load_sample(p, i + 1, dt));
+}
+GF3_DEV double load_sample_clamped(const void* p, int64_t i, int64_t n, int dt) {
+    return (i >= 0 && i < n) ? load_sample(p, i, dt) : 0.0;
+}
+
+// ---------------------------------------------------------------- butterflies
+#define GF3_SQRT1_2 0.70710678118654752440
+
+GF3_DEV void bfly4(cplx* v) {
+    const cplx s0 = cadd(v[0], v[2]), s1 = csub(v[0], v[2]);
+    const cplx s2 = cadd(v[1], v[3]), s3 = mul_negi(csub(v[1], v[3]));
+    v[0] = cadd(s0, s2); v[1] = cadd(s1, s3); v[2] = csub(s0, s2); v[3] = csub(s1, s3);
+}
+
+GF3_DEV void bfly8(cplx* v) {
+    const cplx a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]);
+    const cplx a2 = cadd(v[2], v[6]), a3 = mul_negi(csub(v[2], v[6]));
+    const cplx a4 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    const cplx a6 = cadd(v[3], v[7]), a7 = mul_negi(csub(v[3], v[7]));
+    const cplx b0 = cadd(a0, a2), b1 = cadd(a1, a3), b2 = csub(a0, a2), b3 = csub(a1, a3);
+    const cplx b4 = cadd(a4, a6), o1 = cadd(a5, a7), b6 = mul_negi(csub(a4, a6)), o3 = csub(a5, a7);
+    const cplx b5 = cmk((o1.x + o1.y) * GF3_SQRT1_2, (o1.y - o1.x) * GF3_SQRT1_2);    // * (1-i)/sqrt2
+    const cplx b7 = cmk((o3.y - o3.x) * GF3_SQRT1_2, -(o3.x + o3.y) * GF3_SQRT1_2);   // * (-1-i)/sqrt2
+    v[0] = cadd(b0, b4); v[4] = csub(b0, b4);
+    v[1] = cadd(b1, b5); v[5] = csub(b1, b5);
+    v[2] = cadd(b2, b6); v[6] = csub(b2, b6);
+    v[3] = cadd(b3, b7); v[7] = csub(b3, b7);
+}
+
+template <int R> GF3_DEV void bfly(cplx* v) { if constexpr (R == 8) bfly8(v); else bfly4(v); }
+
+// ---------------------------------------------------------------- LDS FFT
+// LDS footprint of one FFT buffer, in cplx elements (first exchange is padded
+// by one element per 8 to break the stride-8 store conflict).
+template <int NC> struct FftGeom {
+    static constexpr int T = NC / 8;
+    static constexpr int LDS_ELEMS = NC + NC / 8;
+};
+
+template <int NC, int R, int NS>
+GF3_DEV void fft_pass(cplx (&v)[8], cplx* lds, const cplx* __restrict__ tw, int tid) {
+    constexpr int T = NC / 8, NB = 8 / R;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = tid + b * T;
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[b * R + r] = lds[j + r * (NC / R)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = tid + b * T;
+        const int k = j & (NS - 1);
+#pragma unroll
+        for (int r = 1; r < R; ++r) v[b * R + r] = cmul(v[b * R + r], tw[r * k * (NC / (NS * R))]);
+        bfly<R>(&v[b * R]);
+        const int base = (j - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) lds[base + r * NS] = v[b * R + r];
+    }
+    __syncthreads();
+}
+
+// Forward complex FFT of NC points.  In: v[r] = z[tid + r*NC/8].  Out: Z[0..NC)
+// in natural order in lds[0..NC).  tw[m] = exp(-2 pi i m / NC).
+template <int NC>
+GF3_DEV void fft_core(cplx (&v)[8], cplx* lds, const cplx* __restrict__ tw, int tid) {
+    constexpr int T = NC / 8;
+    bfly8(v);
+    __syncthreads();                       // previous users of the buffer are done
+#pragma unroll
+    for (int r = 0; r < 8; ++r) lds[tid * 9 + r] = v[r];          // logical tid*8+r, padded
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { const int i = tid + r * T; v[r] = lds[i + (i >> 3)]; }
+    __syncthreads();
+    {
+        const int k = tid & 7;
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[r * k * (NC / 64)]);
+        bfly8(v);
+        const int base = (tid - k) * 8 + k;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) lds[base + r * 8] = v[r];
+    }
+    __syncthreads();
+    if constexpr (NC == 512) {
+        fft_pass<NC, 8, 64>(v, lds, tw, tid);
+    } else if constexpr (NC == 1024) {
+        fft_pass<NC, 4, 64>(v, lds, tw, tid);
+        fft_pass<NC, 4, 256>(v, lds, tw, tid);
+    } else if constexpr (NC == 2048) {
+        fft_pass<NC, 8, 64>(v, lds, tw, tid);
+        fft_pass<NC, 4, 512>(v, lds, tw, tid);
+    } else {
+        static_assert(NC == 4096, "unsupported FFT size");
+        fft_pass<NC, 8, 64>(v, lds, tw, tid);
+        fft_pass<NC, 8, 512>(v, lds, tw, tid);
+    }
+}
+
+// Bins owned by a thread after the FFT: slot 2m -> bin k[m] = tid + m*NC/8,
+// slot 2m+1 -> bin NC - k[m].  Thread 0's first pair would be (DC, Nyquist),
+// which are not carriers; it owns the self-mirrored bin NC/2 there instead.
+template <int NC> struct PairMap {
+    int k[4];
+    cplx w[4];            // exp(-2 pi i k / (2 NC))
+    GF3_DEV void init(int tid, const cplx* __restrict__ twn) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            k[m] = tid + m * (NC / 8);
+            if (m == 0 && tid == 0) k[m] = NC / 2;
+            w[m] = twn[k[m]];
+        }
+    }
+    // packed-real split: X[k], X[NC-k] of the 2NC-point real DFT from Z in LDS
+    GF3_DEV void split(const cplx* lds, int m, cplx& Xk, cplx& Xm) const {
+        const cplx A = lds[k[m]];
+        const cplx B = cconj(lds[NC - k[m]]);
+        const cplx E = cscale(cadd(A, B), 0.5);
+        const cplx O = cmul(mul_negi(cscale(csub(A, B), 0.5)), w[m]);
+        Xk = cadd(E, O);
+        Xm = cconj(csub(E, O));
+    }
+};
+
+// ---------------------------------------------------------------- block collectives
+GF3_DEV double wave_incl_scan(double x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    return x;
+}
+GF3_DEV double wave_sum(double x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+GF3_DEV double wave_max(double x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x = fmax(x, __shfl_xor(x, d, 64));
+    return x;
+}
+GF3_DEV int wave_min_i(int x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x = min(x, __shfl_xor(x, d, 64));
+    return x;
+}
+// scratch: >= 16 doubles of LDS, not in use by anyone else; contains barriers
+GF3_DEV double block_sum(double x, double* scratch) {
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    x = wave_sum(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wave] = x;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < nw; ++i) s += scratch[i];
+    return s;
+}
+GF3_DEV double block_max(double x, double* scratch) {
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    x = wave_max(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wave] = x;
+    __syncthreads();
+    double s = scratch[0];
+    for (int i = 1; i < nw; ++i) s = fmax(s, scratch[i]);
+    return s;
+}
+GF3_DEV int block_min_i(int x, int* scratch) {
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    x = wave_min_i(x);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wave] = x;
+    __syncthreads();
+    int s = scratch[0];
+    for (int i = 1; i < nw; ++i) s = min(s, scratch[i]);
+    return s;
+}
+// exclusive scan of per-thread totals (two independent scans at once)
+GF3_DEV void block_excl_scan2(double a, double b, double* scratch, double& ea, double& eb) {
+    const int wave = threadIdx.x >> 6;
+    const double ia = wave_incl_scan(a), ib = wave_incl_scan(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) { scratch[wave] = ia; scratch[8 + wave] = ib; }
+    __syncthreads();
+    double oa = 0.0, ob = 0.0;
+    for (int i = 0; i < wave; ++i) { oa += scratch[i]; ob += scratch[8 + i]; }
+    ea = oa + (ia - a);
+    eb = ob + (ib - b);
+}
+
+// np.unwrap's correction for one phase step dd = p[n] - p[n-1]
+GF3_DEV double unwrap_corr(double dd) {
+    const double PI = 3.14159265358979323846, TWO_PI = 6.28318530717958647692;
+    double x = dd + PI;
+    double m = fmod(x, TWO_PI);                 // np.mod: result takes the divisor's sign
+    if (m != 0.0) { if (m < 0.0) m += TWO_PI; } else m = 0.0;
+    double ddmod = m - PI;
+    if (ddmod == -PI && dd > 0.0) ddmod = PI;
+    double corr = ddmod - dd;
+    if (fabs(dd) < PI) corr = 0.0;
+    return corr;
+}

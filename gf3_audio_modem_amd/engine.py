@@ -1,0 +1,280 @@
+"""Engine: torch-tensor front end of libgf3rx (include/gf3rx.h).
+
+PyTorch is used for device memory, streams and (in dist.py) RCCL only; every
+arithmetic step of the receive path runs in the hand-written HIP kernels behind
+the C ABI.  There is no CPU path here: without a GPU or without the built
+library, constructing an Engine raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_TORCH_DT = {_lib.DT_F64: torch.float64, _lib.DT_F32: torch.float32,
+             _lib.DT_I16: torch.int16, _lib.DT_U8: torch.uint8}
+_DT_OF = {v: k for k, v in _TORCH_DT.items()}
+
+
+def qpsk_table():
+    """QPSK Gray table in the reference's mapping_table order (OFDM.py:72-77)."""
+    pts = np.array([(1 + 1j) / np.sqrt(2), (1 - 1j) / np.sqrt(2),
+                    (-1 - 1j) / np.sqrt(2), (-1 + 1j) / np.sqrt(2)])
+    bits = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], dtype=np.uint8)
+    return pts, bits
+
+
+def square_qam_table(mu):
+    """Gray-coded square 2^mu-QAM, unit average energy, points in ascending label
+    order (the reference's demap is table-generic, OFDM.py:484-500)."""
+    if mu % 2 or mu < 2:
+        raise ValueError("Invalid Modulation Type")
+    h = mu // 2
+    L = 1 << h
+    lv = np.zeros(L)
+    for i in range(L):
+        lv[i ^ (i >> 1)] = 2 * i - (L - 1)
+    scale = np.sqrt(2.0 * (L * L - 1) / 3.0)
+    pts, bits = [], []
+    for lab in range(1 << mu):
+        pts.append((lv[lab >> h] + 1j * lv[lab & (L - 1)]) / scale)
+        bits.append([(lab >> (mu - 1 - b)) & 1 for b in range(mu)])
+    return np.array(pts), np.array(bits, dtype=np.uint8)
+
+
+def map_bits(bits2d, const_points, const_bits):
+    """transmitter.map (OFDM.py:196-197): rows of mu bits -> constellation points."""
+    const_bits = np.asarray(const_bits)
+    mu = const_bits.shape[1]
+    w = 1 << np.arange(mu - 1, -1, -1)
+    lut = np.zeros(1 << mu, dtype=complex)
+    lut[(const_bits * w).sum(axis=1)] = const_points
+    return lut[(np.asarray(bits2d, dtype=np.int64) * w).sum(axis=-1)]
+
+
+@dataclass
+class RxConfig:
+    """Python image of gf3_config == the attributes CamG.__init__ sets (OFDM.py:18-101)."""
+    N: int = 4096
+    CP: int = 224
+    P: int = 20
+    D: int = 180
+    data_bins: np.ndarray = None            # data_carriers (OFDM.py:47)
+    const_points: np.ndarray = field(default_factory=lambda: qpsk_table()[0])
+    const_bits: np.ndarray = field(default_factory=lambda: qpsk_table()[1])
+    known_bits: np.ndarray = None           # known_sequence, >= K*mu bits (OFDM.py:99-101)
+    fs: float = 48000.0
+    f0: float = 0.0
+    f1: float = 8000.0
+    thresh: float = 0.4
+    fit_lo: int = 500
+    fit_hi: int = 1000
+    Lc: int = 0
+    in_dtype: torch.dtype = torch.float64
+    max_window: int = 512
+
+    @property
+    def K(self): return self.N // 2 - 1
+    @property
+    def S(self): return self.N + self.CP
+    @property
+    def M(self): return 2 * self.P + self.D
+    @property
+    def mu(self): return int(np.asarray(self.const_bits).shape[1])
+    @property
+    def C(self): return len(self.data_bins)
+    @property
+    def chirp_length(self): return self.Lc if self.Lc > 0 else 5 * self.S
+    @property
+    def frame_len(self): return self.chirp_length + self.M * self.S
+    @property
+    def bits_per_frame(self): return self.D * self.C * self.mu
+
+    def known_symbols(self):
+        kb = np.asarray(self.known_bits[: self.K * self.mu]).reshape(self.K, self.mu)
+        return map_bits(kb, self.const_points, self.const_bits)
+
+
+class Gf3Error(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One gf3_ctx on one GPU."""
+
+    def __init__(self, cfg: RxConfig, device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise Gf3Error("no GPU visible: the gf3rx receive path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if cfg.data_bins is None:
+            raise ValueError("RxConfig.data_bins is required")
+        if cfg.known_bits is None or len(cfg.known_bits) < cfg.K * cfg.mu:
+            raise ValueError("known_bits must hold at least K*mu bits")
+        if cfg.in_dtype not in _DT_OF:
+            raise ValueError(f"unsupported sample dtype {cfg.in_dtype}")
+        self.cfg = cfg
+        pts = np.ascontiguousarray(cfg.const_points, dtype=np.complex128)
+        self._re = np.ascontiguousarray(pts.real)
+        self._im = np.ascontiguousarray(pts.imag)
+        self._bits = np.ascontiguousarray(cfg.const_bits, dtype=np.uint8)
+        kn = cfg.known_symbols()
+        self._kre = np.ascontiguousarray(kn.real)
+        self._kim = np.ascontiguousarray(kn.imag)
+        self._bins = np.ascontiguousarray(cfg.data_bins, dtype=np.int32)
+        g = _lib.Gf3Config(
+            N=cfg.N, CP=cfg.CP, P=cfg.P, D=cfg.D, Lc=cfg.Lc, fs=cfg.fs, f0=cfg.f0, f1=cfg.f1,
+            thresh=cfg.thresh, fit_lo=cfg.fit_lo, fit_hi=cfg.fit_hi, mu=cfg.mu, M=len(pts),
+            const_re=self._re.ctypes.data_as(_lib.c_double_p), const_im=self._im.ctypes.data_as(_lib.c_double_p),
+            const_bits=self._bits.ctypes.data_as(C.POINTER(C.c_uint8)),
+            known_re=self._kre.ctypes.data_as(_lib.c_double_p), known_im=self._kim.ctypes.data_as(_lib.c_double_p),
+            data_bins=self._bins.ctypes.data_as(C.POINTER(C.c_int32)), C=len(self._bins),
+            in_dtype=_DT_OF[cfg.in_dtype], max_window=cfg.max_window)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.gf3_ctx_create(C.byref(g), C.byref(h))
+        if rc != 0:
+            msg = self.lib.gf3_last_error(None).decode()
+            raise (ValueError if rc == _lib.GF3_EINVAL else Gf3Error)(msg)
+        self._h = h
+        self.bytes_per_frame = int(self.lib.gf3_bytes_per_frame(h))
+        self.max_window = int(self.lib.gf3_sync_max_window(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gf3_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.gf3_last_error(self._h).decode()
+            raise (ValueError if rc == _lib.GF3_EINVAL else Gf3Error)(f"gf3rx error {rc}: {msg}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _samples(self, x):
+        """1-D (or any-D contiguous) device tensor of samples in the configured dtype."""
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        if not isinstance(x, torch.Tensor):
+            raise TypeError("samples must be a torch tensor or numpy array")
+        if x.dtype != self.cfg.in_dtype:
+            x = x.to(self.cfg.in_dtype)
+        return x.to(self.device).contiguous()
+
+    def _new(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # ------------------------------------------------------------------ ABI calls
+    def chirp_replica(self):
+        out = np.empty(self.cfg.chirp_length)
+        self._check(self.lib.gf3_chirp_replica(self._h, out.ctypes.data_as(_lib.c_double_p)))
+        return out
+
+    def rfft_batch(self, x, offsets):
+        """[n_sym, N/2+1] complex128 spectra of the N samples starting at each offset."""
+        x = self._samples(x)
+        offsets = torch.as_tensor(offsets, dtype=torch.int64).to(self.device).contiguous()
+        n = offsets.numel()
+        out = self._new((n, self.cfg.N // 2 + 1), torch.complex128)
+        self._check(self.lib.gf3_rfft_batch(self._h, _ptr(x), x.numel(), _ptr(offsets), n, _ptr(out), self._stream()))
+        return out
+
+    def demod_frames(self, x, frame_offsets, want=(), out_bits=None):
+        """Fused a3-a10.  Returns dict with 'bits' (packed uint8
+        [F, bytes_per_frame]) plus any of 'eq','Hs','He','slope','Hest','status'."""
+        cfg = self.cfg
+        x = self._samples(x)
+        off = torch.as_tensor(frame_offsets, dtype=torch.int64).to(self.device).contiguous()
+        F = off.numel()
+        bits = out_bits if out_bits is not None else self._new((F, self.bytes_per_frame), torch.uint8)
+        o = {"bits": bits}
+        if "eq" in want: o["eq"] = self._new((F * cfg.D, cfg.C), torch.complex128)
+        if "Hs" in want: o["Hs"] = self._new((F, cfg.K), torch.complex128)
+        if "He" in want: o["He"] = self._new((F, cfg.K), torch.complex128)
+        if "slope" in want: o["slope"] = self._new((F,), torch.float64)
+        if "Hest" in want: o["Hest"] = self._new((F, cfg.D, cfg.K), torch.complex128)
+        if "status" in want: o["status"] = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self._check(self.lib.gf3_demod_frames(
+            self._h, _ptr(x), x.numel(), _ptr(off), F, _ptr(bits), _ptr(o.get("eq")), _ptr(o.get("Hs")),
+            _ptr(o.get("He")), _ptr(o.get("slope")), _ptr(o.get("Hest")), _ptr(o.get("status")), self._stream()))
+        return o
+
+    def equalise(self, data, start, end, want=("Hest",)):
+        """receiver.equalise on frequency-domain symbols [F,D,K], [F,P,K], [F,P,K]."""
+        cfg = self.cfg
+        dev = lambda a: torch.as_tensor(a, dtype=torch.complex128).to(self.device).contiguous()
+        data, start, end = dev(data), dev(start), dev(end)
+        F = data.shape[0]
+        if tuple(data.shape) != (F, cfg.D, cfg.K) or tuple(start.shape) != (F, cfg.P, cfg.K) or tuple(end.shape) != (F, cfg.P, cfg.K):
+            raise ValueError("equalise: shapes must be [F,D,K], [F,P,K], [F,P,K]")
+        o = {"eq_all": self._new((F * cfg.D, cfg.K), torch.complex128),
+             "Hs": self._new((F, cfg.K), torch.complex128), "He": self._new((F, cfg.K), torch.complex128),
+             "slope": self._new((F,), torch.float64), "bits": self._new((F, self.bytes_per_frame), torch.uint8)}
+        if "Hest" in want: o["Hest"] = self._new((F, cfg.D, cfg.K), torch.complex128)
+        self._check(self.lib.gf3_equalise(
+            self._h, _ptr(data), _ptr(start), _ptr(end), F, _ptr(o["eq_all"]), _ptr(o["Hs"]), _ptr(o["He"]),
+            _ptr(o["slope"]), _ptr(o.get("Hest")), _ptr(o["bits"]), self._stream()))
+        return o
+
+    def sync_frames(self, x, F, stride, win_lo, win_hi, want_peak=False):
+        """Batched windowed chirp sync: first-pilot sample index per frame (int64, -1 = none)."""
+        x = self._samples(x)
+        starts = self._new((F,), torch.int64)
+        peak = self._new((F,), torch.float64) if want_peak else None
+        self._check(self.lib.gf3_sync_frames(self._h, _ptr(x), x.numel(), F, stride, win_lo, win_hi,
+                                             _ptr(starts), _ptr(peak), self._stream()))
+        return (starts, peak) if want_peak else starts
+
+    def sync_stream(self, x, cap=None, want_corr=False):
+        """chirp_method on one stream: indices i with zeros[i] True (int64 tensor)."""
+        x = self._samples(x).reshape(-1)
+        n = x.numel()
+        Lc = self.cfg.chirp_length
+        cap = cap or max(4, n // Lc + 4)
+        peaks = self._new((cap,), torch.int64)
+        ws = int(self.lib.gf3_sync_stream_workspace_bytes(self._h, n))
+        work = self._new((ws,), torch.uint8)
+        corr = self._new((n + Lc - 1,), torch.float64) if want_corr else None
+        cnt = C.c_int64(0)
+        self._check(self.lib.gf3_sync_stream(self._h, _ptr(x), n, _ptr(peaks), cap, C.byref(cnt), _ptr(work),
+                                             _ptr(corr), self._stream()))
+        peaks = peaks[: cnt.value]
+        return (peaks, corr) if want_corr else peaks
+
+    def demap_hard(self, sym):
+        sym = torch.as_tensor(sym, dtype=torch.complex128).to(self.device).contiguous()
+        n = sym.numel()
+        bits = self._new(tuple(sym.shape) + (self.cfg.mu,), torch.uint8)
+        idx = self._new(tuple(sym.shape), torch.uint8)
+        self._check(self.lib.gf3_demap_hard(self._h, _ptr(sym), n, _ptr(bits), _ptr(idx), self._stream()))
+        return bits, idx
+
+    def soft_demap(self, sym, noise_var):
+        sym = torch.as_tensor(sym, dtype=torch.complex128).to(self.device).contiguous()
+        llr = self._new(tuple(sym.shape) + (self.cfg.mu,), torch.float32)
+        self._check(self.lib.gf3_soft_demap(self._h, _ptr(sym), sym.numel(), float(noise_var), _ptr(llr), self._stream()))
+        return llr
+
+    # ------------------------------------------------------------------ bit helpers (layout only)
+    def unpack_bits(self, packed):
+        """[F, bytes_per_frame] uint8 -> [F * D*C*mu] uint8 0/1 (np.unpackbits order), on device."""
+        sh = torch.arange(7, -1, -1, device=packed.device, dtype=torch.uint8)
+        b = (packed.unsqueeze(-1) >> sh) & 1
+        return b.reshape(packed.shape[0], -1)[:, : self.cfg.bits_per_frame].reshape(-1)

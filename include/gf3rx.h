@@ -1,0 +1,177 @@
+/*
+ * gf3rx.h -- C ABI of the MI355X-native OFDM receive-path engine (libgf3rx.so).
+ *
+ * This is the drop-in boundary for the demodulation path of the GF3 audio
+ * modem.  The reference has no FFI of its own (it is one Python file); the
+ * boundary is the set of methods of class `receiver` in /root/reference/OFDM.py
+ * that `receiver.receive` (OFDM.py:581-657) strings together.  Each entry
+ * point below names the reference method(s) it replaces.  INTEGRATION.md shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every call returns 0 (GF3_OK) or a negative
+ *     gf3_status; gf3_last_error(ctx) holds a message for the last failure.
+ *   - every `d_*` pointer is DEVICE memory owned by the caller (e.g. a
+ *     torch tensor's data_ptr()); the library owns only the context and its
+ *     look-up tables.  `stream` is a hipStream_t passed as void* (NULL = the
+ *     default stream).  All work is enqueued asynchronously on that stream;
+ *     only gf3_sync_stream synchronises (it returns a count to the host).
+ *   - a context is immutable after creation: concurrent calls on different
+ *     streams are safe.
+ *   - complex128 arrays are interleaved (re, im) doubles, as NumPy stores them.
+ */
+#ifndef GF3RX_H
+#define GF3RX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF3RX_VERSION "0.1.0"
+
+typedef enum {
+    GF3_OK = 0,
+    GF3_EINVAL = -1,      /* bad argument / unsupported geometry            */
+    GF3_EHIP = -2,        /* a HIP runtime call failed                      */
+    GF3_ENOMEM = -3,
+    GF3_ERANGE = -4,      /* capacity of an output buffer exceeded          */
+    GF3_ENODETECT = -5    /* sync found fewer than two chirps (the reference
+                             dies in np.vstack([]) here, OFDM.py:400)       */
+} gf3_status;
+
+/* storage type of the input sample stream (samples are widened to fp64 in
+ * registers; all arithmetic is fp64) */
+typedef enum { GF3_F64 = 0, GF3_F32 = 1, GF3_I16 = 2, GF3_U8 = 3 } gf3_dtype;
+
+/*
+ * Engine configuration == the attributes CamG.__init__ sets (OFDM.py:18-101),
+ * generalised: any N in {1024,2048,4096,8192}, any CP, any constellation.
+ */
+typedef struct {
+    int32_t N;                  /* ofdm_symbol_size            OFDM.py:27   */
+    int32_t CP;                 /* cp_length                   OFDM.py:42   */
+    int32_t P;                  /* no_pilots (each side), >=1  OFDM.py:51   */
+    int32_t D;                  /* packet_length               OFDM.py:50   */
+    int32_t Lc;                 /* chirp_length; 0 => 5*(N+CP) OFDM.py:64   */
+    double  fs, f0, f1;         /* 48000, 0, 8000              OFDM.py:24,62-63 */
+    double  thresh;             /* 0.4                         OFDM.py:361  */
+    int32_t fit_lo, fit_hi;     /* 500, 1000 (python slice)    OFDM.py:462  */
+    int32_t mu;                 /* bits per constellation point             */
+    int32_t M;                  /* constellation size (<= 64)               */
+    const double  *const_re;    /* [M] points in mapping_table insertion    */
+    const double  *const_im;    /*     order                   OFDM.py:72-77 */
+    const uint8_t *const_bits;  /* [M*mu] bit labels, tuple order           */
+    const double  *known_re;    /* [K] map(known_sequence[:K*mu]) OFDM.py:429 */
+    const double  *known_im;    /*     K = N/2-1                            */
+    const int32_t *data_bins;   /* [C] data_carriers (FFT bin numbers 1..K),
+                                   output bit order follows this array  OFDM.py:47,603 */
+    int32_t C;
+    int32_t in_dtype;           /* gf3_dtype of the sample stream           */
+    int32_t max_window;         /* largest search window (lags) gf3_sync_frames
+                                   will be asked for; 0 => 512               */
+} gf3_config;
+
+typedef struct gf3_ctx gf3_ctx;
+
+const char *gf3_version(void);
+
+/* replaces CamG.__init__ + sync_chirp (OFDM.py:18-109): builds twiddles, the
+ * chirp replica and its partition spectra, demap tables, on the current device */
+int gf3_ctx_create(const gf3_config *cfg, gf3_ctx **out);
+void gf3_ctx_destroy(gf3_ctx *ctx);
+const char *gf3_last_error(const gf3_ctx *ctx);
+
+/* derived sizes a caller needs to allocate outputs */
+int32_t gf3_bytes_per_frame(const gf3_ctx *ctx);     /* ceil(D*C*mu/8)            */
+int32_t gf3_sync_max_window(const gf3_ctx *ctx);     /* lags one gf3_sync_frames block resolves */
+int64_t gf3_sync_stream_workspace_bytes(const gf3_ctx *ctx, int64_t n);
+
+/* chirp replica, Lc doubles, copied to HOST memory (sync_chirp, OFDM.py:106-109) */
+int gf3_chirp_replica(const gf3_ctx *ctx, double *h_out);
+
+/*
+ * remove_cp + np.fft.fft (OFDM.py:407-408, 593) on n_sym independent symbols.
+ * d_offsets[i] = index (in samples, into d_in) of the first of the N samples of
+ * symbol i (i.e. already past its cyclic prefix).  Output: [n_sym, N/2+1]
+ * complex128, bins 0..N/2 of the unnormalised forward DFT.
+ */
+int gf3_rfft_batch(gf3_ctx *ctx, const void *d_in, int64_t n_in,
+                   const int64_t *d_offsets, int64_t n_sym,
+                   void *d_out_c128, void *stream);
+
+/*
+ * get_symbols + remove_cp + fft + get_data + equalise + data-carrier select +
+ * demap + PS (OFDM.py:391-505, 593, 603) fused, one packet ("frame") per
+ * workgroup.  d_frame_offsets[f] = sample index of the first pilot symbol's
+ * cyclic prefix (what get_symbols computes as peak+2, OFDM.py:393).
+ *
+ *   d_bits_packed  [F, gf3_bytes_per_frame] uint8, MSB-first (np.packbits order),
+ *                  bit order packet -> symbol -> data carrier -> bit (OFDM.py:505)
+ *   d_eq           optional [F*D, C] complex128: equalised data-carrier symbols
+ *   d_Hs, d_He     optional [F, K]   complex128: Hest_start / Hest_end (OFDM.py:450-451)
+ *   d_slope        optional [F]      float64   : polyfit slope p (OFDM.py:462)
+ *   d_Hest         optional [F, D, K] complex128: channel model (OFDM.py:471-475)
+ * A frame whose samples fall outside [0, n_in) decodes to zero bits and sets
+ * bit 0 of *d_status (optional int32 on the device).
+ */
+int gf3_demod_frames(gf3_ctx *ctx, const void *d_in, int64_t n_in,
+                     const int64_t *d_frame_offsets, int64_t F,
+                     uint8_t *d_bits_packed, void *d_eq, void *d_Hs, void *d_He,
+                     double *d_slope, void *d_Hest, int32_t *d_status, void *stream);
+
+/*
+ * receiver.equalise as a stand-alone stage (OFDM.py:422-480): the same kernel
+ * as gf3_demod_frames, fed with frequency-domain symbols instead of samples.
+ *   d_data [F, D, K], d_start [F, P, K], d_end [F, P, K] complex128 (get_data's outputs)
+ *   d_eq_all [F*D, K] complex128 (all carriers, as the reference returns)
+ *   d_Hs, d_He, d_slope, d_Hest: as above, optional;  d_bits: packed decisions
+ *   on the data carriers (required scratch/out, [F, gf3_bytes_per_frame]).
+ */
+int gf3_equalise(gf3_ctx *ctx, const void *d_data, const void *d_start, const void *d_end,
+                 int64_t F, void *d_eq_all, void *d_Hs, void *d_He, double *d_slope,
+                 void *d_Hest, uint8_t *d_bits, void *stream);
+
+/*
+ * chirp_method + the '+2' of get_symbols (OFDM.py:356-372, 393) for a batch of
+ * independent frame buffers: frame f is searched for a chirp START in sample
+ * range [f*stride + win_lo, f*stride + win_hi).  Peak rule as the reference:
+ * correlation normalised by the window maximum, first local extremum above
+ * `thresh`.  d_starts[f] = sample index of the first pilot symbol (chirp start +
+ * Lc), ready to be passed to gf3_demod_frames; -1 where nothing qualifies.
+ */
+int gf3_sync_frames(gf3_ctx *ctx, const void *d_in, int64_t n_in,
+                    int64_t F, int64_t stride, int32_t win_lo, int32_t win_hi,
+                    int64_t *d_starts, double *d_peak_or_null, void *stream);
+
+/*
+ * chirp_method with full reference semantics on one contiguous stream
+ * (OFDM.py:356-372): full-coverage matched filter, normalisation by the GLOBAL
+ * maximum, extremum-and-threshold candidates, sequential non-max suppression
+ * over Lc samples, and the except-branch that drops every detection when a
+ * chirp ends within the last two samples.  Writes the indices i with
+ * zeros[i]==True (ascending) to d_peaks (capacity cap) and their count to
+ * *n_peaks (host).  d_work: gf3_sync_stream_workspace_bytes(ctx, n) bytes.
+ * d_corr (optional, n+Lc-1 doubles) receives the raw correlation P (OFDM.py:358).
+ */
+int gf3_sync_stream(gf3_ctx *ctx, const void *d_r, int64_t n,
+                    int64_t *d_peaks, int64_t cap, int64_t *n_peaks,
+                    void *d_work, double *d_corr_or_null, void *stream);
+
+/*
+ * demap (OFDM.py:484-500) standalone: hard decisions for n symbols.
+ * d_bits_u8: [n*mu] one byte per bit (0/1); d_idx_u8 (optional): [n] index of
+ * the chosen constellation point (hardDecision = constellation[idx]).
+ */
+int gf3_demap_hard(gf3_ctx *ctx, const void *d_sym_c128, int64_t n,
+                   uint8_t *d_bits_u8, uint8_t *d_idx_u8, void *stream);
+
+/* max-log soft demapping (not in the reference; LLR > 0 <=> bit 0). [n*mu] f32 */
+int gf3_soft_demap(gf3_ctx *ctx, const void *d_sym_c128, int64_t n,
+                   double noise_var, float *d_llr_f32, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GF3RX_H */

@@ -269,8 +269,19 @@ def make_realrec(OFDM):
     )
 
 
+def make_known_bits():
+    """The modem standard's pilot bit sequence (Handouts/random_bits.txt, read by
+    CamG.__init__ OFDM.py:99-101), packed, shipped with the package as data."""
+    bits = orc.load_known_bits(os.path.join(REF, "Handouts", "random_bits.txt"), 12000)
+    out = os.path.join(REPO, "gf3_audio_modem_amd", "data", "known_bits.npz")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    np.savez_compressed(out, packed=np.packbits(bits), n=len(bits))
+    print("known_bits.npz written:", len(bits), "bits")
+
+
 def main():
     OFDM = import_reference()
+    make_known_bits()
     which = set(sys.argv[1:]) or {"g1", "g1b", "g2", "g3", "g4", "g5", "g6", "g7", "g8"}
     h = np.loadtxt(os.path.join(REF, "Handouts", "gr5channel.csv")).reshape(-1)
     if "g1" in which:
