@@ -728,6 +728,7 @@ extern "C" int gf3_chirp_replica(const gf3_ctx* c, double* h_out) {
 
 extern "C" int gf3_rfft_batch(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_offsets, int64_t n_sym,
                               void* d_out, void* stream) {
+    if (c && n_sym == 0) return GF3_OK;
     if (!c || !d_in || !d_offsets || !d_out || n_sym < 0) return fail(c, GF3_EINVAL, "gf3_rfft_batch: bad argument");
     HIPCHK(c, run_rfft(c, d_in, n_in, c->cfg.in_dtype, d_offsets, n_sym, (cplx*)d_out, (hipStream_t)stream));
     return GF3_OK;
@@ -740,6 +741,7 @@ static size_t demod_lds_bytes(const gf3_ctx* c) {
 extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,
                                 uint8_t* d_bits, void* d_eq, void* d_Hs, void* d_He, double* d_slope, void* d_Hest,
                                 int32_t* d_status, void* stream) {
+    if (c && F == 0) return GF3_OK;
     if (!c || !d_in || !d_off || !d_bits || F < 0) return fail(c, GF3_EINVAL, "gf3_demod_frames: bad argument");
     const gf3_config& g = c->cfg;
     DemodArgs a{{c->d_tw, c->d_twn}, d_in, n_in, d_off, g.in_dtype,
@@ -757,6 +759,7 @@ extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, cons
 extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start, const void* d_end, int64_t F,
                             void* d_eq_all, void* d_Hs, void* d_He, double* d_slope, void* d_Hest,
                             uint8_t* d_bits, void* stream) {
+    if (c && F == 0) return GF3_OK;
     if (!c || !d_data || !d_start || !d_end || !d_bits || F < 0) return fail(c, GF3_EINVAL, "gf3_equalise: bad argument");
     const gf3_config& g = c->cfg;
     DemodArgs a{{c->d_tw, c->d_twn}, nullptr, 0, nullptr, g.in_dtype,
@@ -780,6 +783,7 @@ static hipError_t run_corr(const gf3_ctx* c, const CorrArgs& a, int64_t grid, hi
 
 extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64_t F, int64_t stride,
                                int32_t win_lo, int32_t win_hi, int64_t* d_starts, double* d_peak, void* stream) {
+    if (c && F == 0) return GF3_OK;
     if (!c || !d_in || !d_starts || F < 0) return fail(c, GF3_EINVAL, "gf3_sync_frames: bad argument");
     const int W = win_hi - win_lo;
     const CorrPlan& pl = c->frames_plan;
@@ -867,10 +871,12 @@ static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, ui
     return GF3_OK;
 }
 extern "C" int gf3_demap_hard(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* d_bits, uint8_t* d_idx, void* stream) {
+    if (c && n == 0) return GF3_OK;
     if (!c || !d_sym || !d_bits || n < 0) return fail(c, GF3_EINVAL, "gf3_demap_hard: bad argument");
     return run_demap(c, d_sym, n, d_bits, d_idx, nullptr, 1.0, stream);
 }
 extern "C" int gf3_soft_demap(gf3_ctx* c, const void* d_sym, int64_t n, double noise_var, float* d_llr, void* stream) {
+    if (c && n == 0) return GF3_OK;
     if (!c || !d_sym || !d_llr || n < 0 || !(noise_var > 0)) return fail(c, GF3_EINVAL, "gf3_soft_demap: bad argument");
     return run_demap(c, d_sym, n, nullptr, nullptr, d_llr, noise_var, stream);
 }
