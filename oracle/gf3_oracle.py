@@ -434,3 +434,34 @@ def tx_stream(bits, fill_syms, p: RxParams, gaps=None, lead=0, tail=2):
         parts += [np.zeros(int(gaps[f])), rows[f]]
     parts += [chirp_replica(p), np.zeros(tail)]
     return np.concatenate(parts)
+
+
+# --------------------------------------------------------------------------
+# batched frame buffers (the engine's gf3_sync_frames + gf3_demod_frames path):
+# every row is an independent capture holding one chirp-prefixed packet.
+# --------------------------------------------------------------------------
+
+def sync_rows(rows, p: RxParams, win_lo, win_hi):
+    """Per row: the reference's matched filter (OFDM.py:357-358) over the row, then
+    its peak rule (:359-361) restricted to chirp-start lags [win_lo, win_hi):
+    normalise by the window maximum, first local extremum above thresh.
+    Returns the first-pilot sample index within each row (-1: none)."""
+    out = np.full(len(rows), -1, dtype=np.int64)
+    for f, row in enumerate(rows):
+        P = matched_filter(row, p)
+        seg = P[win_lo + p.Lc - 1: win_hi + p.Lc - 1]
+        pn = seg / np.amax(seg)
+        d = np.diff(pn)
+        cand = np.flatnonzero(((d[:-1] * d[1:]) <= 0) & (pn[1:-1] > p.thresh))
+        if len(cand):
+            out[f] = win_lo + cand[0] + 1 + p.Lc
+    return out
+
+
+def receive_rows(rows, p: RxParams, win_lo, win_hi):
+    rows = np.asarray(rows)
+    st = sync_rows(rows, p, win_lo, win_hi)
+    stride = rows.shape[1]
+    out = demod_frames(rows.reshape(-1), st + np.arange(len(rows)) * stride, p)
+    out["starts"] = st
+    return out
