@@ -29,8 +29,9 @@ struct DemodArgs {
     FftTables t;
     const void* in; int64_t n_in; const int64_t* off; int dt;
     int CP, S, P, D, K, C, mu, M;
-    const cplx* known;        // [K]
+    const cplx* inv_known;    // [K] 1/known symbol
     const int* pos;           // [K] data-carrier position or -1
+    int contig_lo;            // >0: data bins are contig_lo .. contig_lo+C-1 in order (no table look-up)
     const double* cre; const double* cim; const int* clab;   // [M]
     int fit_lo, fit_hi;       // effective python-slice bounds, fit_hi <= K
     double xbar, inv_sxx;
@@ -41,7 +42,12 @@ struct DemodArgs {
     const cplx* sp_start;     // [F, P, K]
     const cplx* sp_end;       // [F, P, K]
     cplx* eq_all;             // [F*D, K] equalised symbols on all carriers
+    int qpsk_fast;            // table is the reference QPSK table: decide by signs away from ties
 };
+
+// occupancy targets: min waves per SIMD handed to __launch_bounds__ (blocks of NC/8 threads).
+// 2048 -> 3 blocks of 4 waves per CU (<=168 VGPRs), 4096 -> 1 block of 8 waves (<=256).
+template <int NC> struct Occ { static constexpr int WPS = 2; };
 
 struct CorrArgs {
     FftTables t;
@@ -58,8 +64,8 @@ struct CorrArgs {
 // ============================================================================
 // standalone batched real FFT  (remove_cp + np.fft.fft, OFDM.py:407-408,593)
 // ============================================================================
-template <int NC>
-__global__ __launch_bounds__(NC / 8) void rfft_kernel(RfftArgs a) {
+template <int NC, int DT>
+__global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void rfft_kernel(RfftArgs a) {
     extern __shared__ double2 smem[];
     constexpr int T = NC / 8;
     const int tid = threadIdx.x;
@@ -68,18 +74,23 @@ __global__ __launch_bounds__(NC / 8) void rfft_kernel(RfftArgs a) {
     cplx* out = a.out + sym * (int64_t)(NC + 1);
     PairMap<NC> pm;
     pm.init(tid, a.t.twn);
+    FftTw<NC> ft;
+    ft.init(tid, a.t.tw);
     cplx v[8];
     const bool ok = off >= 0 && off + 2 * NC <= a.n_in;
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-        v[r] = ok ? load_pair(a.in, off + 2 * (int64_t)(tid + r * T), a.dt) : cmk(0.0, 0.0);
-    fft_core<NC>(v, smem, a.t.tw, tid);
+    for (int r = 0; r < 8; ++r) {
+        RawPair<DT> raw;
+        if (ok) raw.load(a.in, off + 2 * (int64_t)(tid + r * T)); else raw.zero();
+        v[r] = raw.get();
+    }
+    fft_core<NC>(v, smem, ft, tid);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         cplx Xk, Xm;
         pm.split(smem, m, Xk, Xm);
-        out[pm.k[m]] = Xk;
-        if (!(tid == 0 && m == 0)) out[NC - pm.k[m]] = Xm;
+        out[pm.k(m)] = Xk;
+        if (!(tid == 0 && m == 0)) out[NC - pm.k(m)] = Xm;
     }
     if (tid == 0) {
         const cplx z0 = smem[0];
@@ -91,9 +102,14 @@ __global__ __launch_bounds__(NC / 8) void rfft_kernel(RfftArgs a) {
 // ============================================================================
 // fused demodulation of one packet per workgroup
 // (get_symbols..PS, OFDM.py:391-505; equalise :422-480 is the bulk)
+//
+// Per thread: 8 carriers ("slots": bins tid+m*T and NC-tid-m*T), whose channel
+// state (unit phasor of Hs, |Hs|, |He|-|Hs|) stays in registers for the whole
+// packet.  Symbols are processed start pilots -> end pilots -> data, the next
+// symbol's raw samples being fetched while the current one is transformed.
 // ============================================================================
-template <int NC, bool SPECTRA>
-__global__ __launch_bounds__(NC / 8) void demod_kernel(DemodArgs a) {
+template <int NC, int DT, bool SPECTRA>
+__global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a) {
     extern __shared__ double2 smem[];
     constexpr int T = NC / 8;
     cplx* lds = smem;
@@ -119,66 +135,84 @@ __global__ __launch_bounds__(NC / 8) void demod_kernel(DemodArgs a) {
 
     PairMap<NC> pm;
     pm.init(tid, a.t.twn);
-    int bin[8];
-    bool valid[8];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        bin[2 * m] = pm.k[m];
-        bin[2 * m + 1] = NC - pm.k[m];
-        valid[2 * m] = true;
-        valid[2 * m + 1] = !(tid == 0 && m == 0);
-    }
+    FftTw<NC> ft;
+    ft.init(tid, a.t.tw);
+    // slot s = 2m+h: bin of the carrier it holds, whether it is a real slot, its data position
+    auto bin_of = [&](int s) { const int kk = pm.k(s >> 1); return (s & 1) ? NC - kk : kk; };
+    auto live_of = [&](int s) { return !(tid == 0 && s == 1); };          // thread 0, slot 1 repeats bin NC/2
+    auto pos_of = [&](int s) {
+        if (!live_of(s)) return -1;
+        const int bn = bin_of(s);
+        if (a.contig_lo > 0) return (bn >= a.contig_lo && bn < a.contig_lo + a.C) ? bn - a.contig_lo : -1;
+        return a.pos[bn - 1];
+    };
 
+    // symbol order: start pilots, end pilots, data (position in the packet)
+    auto sym_pos = [&](int i) { return i < P ? i : (i < 2 * P ? D + i : i - P); };
+    RawPair<DT> nxt[8];
+    auto fetch = [&](int i) {
+        const int64_t s0 = off + (int64_t)sym_pos(i) * S + a.CP;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) nxt[r].load(a.in, s0 + 2 * (int64_t)(tid + r * T));
+    };
+    const int Msym = 2 * P + D;
     cplx v[8];
+    auto transform = [&](int i) {                     // nxt -> spectrum Z in LDS; prefetch i+1
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
+        if (i + 1 < Msym) fetch(i + 1);
+        fft_core<NC>(v, lds, ft, tid);
+    };
+    if constexpr (!SPECTRA) fetch(0);
+
     // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451)
     cplx Hs[8], He[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) Hs[s] = He[s] = cmk(0.0, 0.0);
-    for (int side = 0; side < 2; ++side) {
-        for (int p = 0; p < P; ++p) {
-            const int symi = side ? (P + D + p) : p;
-            const cplx* sp = nullptr;
-            if constexpr (SPECTRA) {
-                sp = (side ? a.sp_end : a.sp_start) + ((int64_t)f * P + p) * K;
-            } else {
-                const int64_t s0 = off + (int64_t)symi * S + a.CP;
+    for (int i = 0; i < 2 * P; ++i) {
+        const bool side = i >= P;
+        const cplx* sp = nullptr;
+        if constexpr (SPECTRA) sp = (side ? a.sp_end : a.sp_start) + ((int64_t)f * P + (side ? i - P : i)) * K;
+        else transform(i);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = load_pair(a.in, s0 + 2 * (int64_t)(tid + r * T), a.dt);
-                fft_core<NC>(v, lds, a.t.tw, tid);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                cplx Xk, Xm;
-                if constexpr (SPECTRA) { Xk = sp[bin[2 * m] - 1]; Xm = sp[bin[2 * m + 1] - 1]; }
-                else pm.split(lds, m, Xk, Xm);
-                if (side) { He[2 * m] = cadd(He[2 * m], Xk); He[2 * m + 1] = cadd(He[2 * m + 1], Xm); }
-                else      { Hs[2 * m] = cadd(Hs[2 * m], Xk); Hs[2 * m + 1] = cadd(Hs[2 * m + 1], Xm); }
-            }
-        }
-    }
-    const double dP = (double)P;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const cplx kn = a.known[bin[s] - 1];
-        Hs[s] = cdiv_np(cmk(Hs[s].x / dP, Hs[s].y / dP), kn);
-        He[s] = cdiv_np(cmk(He[s].x / dP, He[s].y / dP), kn);
-        if (valid[s]) {
-            if (a.Hs) a.Hs[f * K + bin[s] - 1] = Hs[s];
-            if (a.He) a.He[f * K + bin[s] - 1] = He[s];
+        for (int m = 0; m < 4; ++m) {
+            cplx Xk, Xm;
+            if constexpr (SPECTRA) { Xk = sp[bin_of(2 * m) - 1]; Xm = sp[bin_of(2 * m + 1) - 1]; }
+            else pm.split(lds, m, Xk, Xm);
+            if (side) { He[2 * m] = cadd(He[2 * m], Xk); He[2 * m + 1] = cadd(He[2 * m + 1], Xm); }
+            else      { Hs[2 * m] = cadd(Hs[2 * m], Xk); Hs[2 * m + 1] = cadd(Hs[2 * m + 1], Xm); }
         }
     }
 
-    // ---- phase slope: unwrap(angle(He)) - unwrap(angle(Hs)), LS fit (OFDM.py:454-462)
-    double th0[8];
+    // ---- per carrier: H = mean / known; phases to LDS; equaliser state
+    //      Hest = (a0 + da f_l) u exp(j slope n f_l),  u = Hs/|Hs| = exp(j angle(Hs))
     __syncthreads();                                  // all reads of Z done; reuse the buffer
     double* ph0 = (double*)lds;
     double* ph1 = ph0 + NC;
+    cplx u[8];
+    double a0[8], da[8];
+    const double dP = (double)P;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        th0[s] = atan2(Hs[s].y, Hs[s].x);
-        if (valid[s]) { ph0[bin[s] - 1] = th0[s]; ph1[bin[s] - 1] = atan2(He[s].y, He[s].x); }
+        const int bn = bin_of(s);
+        const cplx ik = a.inv_known[bn - 1];
+        const cplx hs = cmul(cmk(Hs[s].x / dP, Hs[s].y / dP), ik);
+        const cplx he = cmul(cmk(He[s].x / dP, He[s].y / dP), ik);
+        if (live_of(s)) {
+            if (a.Hs) a.Hs[f * K + bn - 1] = hs;
+            if (a.He) a.He[f * K + bn - 1] = he;
+            ph0[bn - 1] = atan2(hs.y, hs.x);
+            ph1[bn - 1] = atan2(he.y, he.x);
+        }
+        a0[s] = sqrt(hs.x * hs.x + hs.y * hs.y);
+        da[s] = sqrt(he.x * he.x + he.y * he.y) - a0[s];
+        const double ia = 1.0 / a0[s];
+        u[s] = cmk(hs.x * ia, hs.y * ia);
+        __builtin_amdgcn_sched_barrier(0);            // one carrier at a time: keeps live ranges short
     }
     __syncthreads();
+
+    // ---- phase slope: unwrap(angle(He)) - unwrap(angle(Hs)), LS fit (OFDM.py:454-462)
     double slope;
     {
         const int n0 = tid * 8;
@@ -207,15 +241,6 @@ __global__ __launch_bounds__(NC / 8) void demod_kernel(DemodArgs a) {
     }
     if (tid == 0 && a.slope) a.slope[f] = slope;
 
-    // ---- per-carrier equaliser state in registers
-    double a0[8], da[8];
-    int pos[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        a0[s] = hypot(Hs[s].x, Hs[s].y);
-        da[s] = hypot(He[s].x, He[s].y) - a0[s];
-        pos[s] = valid[s] ? a.pos[bin[s] - 1] : -1;
-    }
     for (int i = tid; i < nwords; i += T) bitbuf[i] = 0;
     // (fft_core's first barrier also orders this zeroing before the atomics)
 
@@ -223,52 +248,63 @@ __global__ __launch_bounds__(NC / 8) void demod_kernel(DemodArgs a) {
     const double denom = (double)(D + P);
     for (int l = 0; l < D; ++l) {
         const cplx* sp = nullptr;
-        if constexpr (SPECTRA) {
-            sp = a.sp_data + ((int64_t)f * D + l) * K;
-            __syncthreads();
-        } else {
-            const int64_t s0 = off + (int64_t)(P + l) * S + a.CP;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = load_pair(a.in, s0 + 2 * (int64_t)(tid + r * T), a.dt);
-            fft_core<NC>(v, lds, a.t.tw, tid);
-        }
-        const double lf = (double)l + 0.5 * (double)P;
+        if constexpr (SPECTRA) { sp = a.sp_data + ((int64_t)f * D + l) * K; __syncthreads(); }
+        else transform(2 * P + l);
+        const double fl = ((double)l + 0.5 * (double)P) / denom;          // (l + P/2)/(D+P)
+        const double phi = slope * fl;                                     // phase per carrier index
+        // exp(j phi n): slots 2m have n = (tid-1) + mT, slots 2m+1 have n = (NC-1-tid) - mT
+        cplx rA = cis_fast(phi * (double)(tid - 1));
+        cplx rB = cis_fast(phi * (double)(NC - 1 - tid));
+        const cplx rC = cis_fast(phi * (double)T);
+        if (tid == 0) rA = cis_fast(phi * (double)(NC / 2 - 1));          // slot 0 of thread 0 is bin NC/2 ...
+        const cplx rA1 = cis_fast(phi * (double)(T - 1));                  // ... and it rejoins the pattern at m = 1
         const int w0 = (l * Bs) >> 5;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             cplx X[2];
-            if constexpr (SPECTRA) { X[0] = sp[bin[2 * m] - 1]; X[1] = sp[bin[2 * m + 1] - 1]; }
+            if constexpr (SPECTRA) { X[0] = sp[bin_of(2 * m) - 1]; X[1] = sp[bin_of(2 * m + 1) - 1]; }
             else pm.split(lds, m, X[0], X[1]);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int s = 2 * m + h;
-                const int n = bin[s] - 1;
-                const double mag = a0[s] + da[s] * lf / denom;
-                const double phase = slope * (double)n * lf / denom;
-                double sn, cs;
-                sincos(th0[s] + phase, &sn, &cs);
-                const cplx Hh = cmk(mag * cs, mag * sn);
-                const cplx e = cdiv_np(X[h], Hh);
-                if (valid[s] && a.Hest) a.Hest[((int64_t)f * D + l) * K + n] = Hh;
-                if (valid[s] && a.eq_all) a.eq_all[((int64_t)f * D + l) * K + n] = e;
-                if (pos[s] >= 0) {
-                    if (a.eq) a.eq[((int64_t)f * D + l) * a.C + pos[s]] = e;
-                    int best = 0;
-                    double dx = e.x - a.cre[0], dy = e.y - a.cim[0];
-                    double bd = dx * dx + dy * dy;
-                    for (int c = 1; c < a.M; ++c) {
-                        dx = e.x - a.cre[c]; dy = e.y - a.cim[c];
-                        const double d = dx * dx + dy * dy;
-                        if (d < bd) { bd = d; best = c; }
+                const int n = bin_of(s) - 1;
+                const bool live = live_of(s);
+                const double mag = fma(da[s], fl, a0[s]);
+                const cplx g = cmul(u[s], h ? rB : rA);                    // unit phasor of Hest
+                const double inv = 1.0 / mag;
+                const cplx e = cscale(cmul_conj(X[h], g), inv);            // X / (mag g)
+                if (live && a.Hest) a.Hest[((int64_t)f * D + l) * K + n] = cscale(g, mag);
+                if (live && a.eq_all) a.eq_all[((int64_t)f * D + l) * K + n] = e;
+                const int ps = pos_of(s);
+                if (ps >= 0) {
+                    if (a.eq) a.eq[((int64_t)f * D + l) * a.C + ps] = e;
+                    uint32_t lab;
+                    const bool easy = a.qpsk_fast &&
+                        (fmin(fabs(e.x), fabs(e.y)) > 1e-6 * (1.0 + e.x * e.x + e.y * e.y));
+                    if (easy) {
+                        lab = (e.y < 0.0 ? 2u : 0u) | (e.x < 0.0 ? 1u : 0u);
+                    } else {                                              // literal table scan (OFDM.py:493-496)
+                        int best = 0;
+                        double dx = e.x - a.cre[0], dy = e.y - a.cim[0];
+                        double bd = dx * dx + dy * dy;
+                        for (int c = 1; c < a.M; ++c) {
+                            dx = e.x - a.cre[c]; dy = e.y - a.cim[c];
+                            const double d = dx * dx + dy * dy;
+                            if (d < bd) { bd = d; best = c; }
+                        }
+                        lab = (uint32_t)a.clab[best];
                     }
-                    const uint32_t lab = (uint32_t)a.clab[best];
-                    const int o = (l * a.C + pos[s]) * a.mu;
+                    const int o = (l * a.C + ps) * a.mu;
                     const uint64_t val = (uint64_t)lab << (64 - a.mu - (o & 31));
                     const int w = (o >> 5) - w0;
                     atomicOr(&bitbuf[w], (uint32_t)(val >> 32));
                     if ((uint32_t)val) atomicOr(&bitbuf[w + 1], (uint32_t)val);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
+            // advance the carrier-index rotations to m+1
+            rA = (m == 0 && tid == 0) ? rA1 : cmul(rA, rC);
+            rB = cmul_conj(rB, rC);
         }
         __syncthreads();
         // flush the words this symbol completed; carry the partial one
@@ -300,8 +336,8 @@ __global__ __launch_bounds__(NC / 8) void demod_kernel(DemodArgs a) {
 //   c split into Q partitions of Lp taps; each partition's contribution is a
 //   circular correlation of size N = 2NC, valid for lags < N-Lp+1.
 // ============================================================================
-template <int NC>
-__global__ __launch_bounds__(NC / 8) void corr_kernel(CorrArgs a) {
+template <int NC, int DT>
+__global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) {
     extern __shared__ double2 smem[];
     constexpr int T = NC / 8;
     cplx* lds = smem;
@@ -321,29 +357,46 @@ __global__ __launch_bounds__(NC / 8) void corr_kernel(CorrArgs a) {
 
     PairMap<NC> pm;
     pm.init(tid, a.t.twn);
+    FftTw<NC> ft;
+    ft.init(tid, a.t.tw);
     cplx acc[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc[s] = cmk(0.0, 0.0);
     double accDC = 0.0, accNy = 0.0;
     const int need = a.Lp + a.Wmax - 1;           // samples of a segment that reach valid lags
-    cplx v[8];
-    for (int q = 0; q < a.Q; ++q) {
+    // a segment that lies wholly inside the buffer can use unguarded pair loads
+    RawPair<DT> nxt[8];
+    auto fetch = [&](int q) {
         const int64_t seg = s0 + (int64_t)q * a.Lp;
-        const cplx* Hq = a.Hq + (int64_t)q * (NC + 1);
+        const bool inside = seg >= 0 && seg + 2 * NC <= a.n_in;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int j = 2 * (tid + r * T);
-            const double x0 = (j < need) ? load_sample_clamped(a.in, seg + j, a.n_in, a.dt) : 0.0;
-            const double x1 = (j + 1 < need) ? load_sample_clamped(a.in, seg + j + 1, a.n_in, a.dt) : 0.0;
-            v[r] = cmk(x0, x1);
+            if (inside && j + 1 < need) nxt[r].load(a.in, seg + j);
+            else {
+                nxt[r].zero();
+                if (j < need && seg + j >= 0 && seg + j < a.n_in) nxt[r].v.a = ((const typename RawT<DT>::E*)a.in)[seg + j];
+                if (j + 1 < need && seg + j + 1 >= 0 && seg + j + 1 < a.n_in) nxt[r].v.b = ((const typename RawT<DT>::E*)a.in)[seg + j + 1];
+            }
         }
-        fft_core<NC>(v, lds, a.t.tw, tid);
+    };
+    fetch(0);
+    cplx v[8];
+    for (int q = 0; q < a.Q; ++q) {
+        const cplx* Hq = a.Hq + (int64_t)q * (NC + 1);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
+        if (q + 1 < a.Q) fetch(q + 1);
+        cplx hq[8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { hq[2 * m] = Hq[pm.k(m)]; hq[2 * m + 1] = Hq[NC - pm.k(m)]; }
+        fft_core<NC>(v, lds, ft, tid);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             cplx Xk, Xm;
             pm.split(lds, m, Xk, Xm);
-            acc[2 * m] = cadd(acc[2 * m], cmul_conj(Xk, Hq[pm.k[m]]));
-            acc[2 * m + 1] = cadd(acc[2 * m + 1], cmul_conj(Xm, Hq[NC - pm.k[m]]));
+            acc[2 * m] = cadd(acc[2 * m], cmul_conj(Xk, hq[2 * m]));
+            acc[2 * m + 1] = cadd(acc[2 * m + 1], cmul_conj(Xm, hq[2 * m + 1]));
         }
         if (tid == 0) {
             const cplx z0 = lds[0];
@@ -358,11 +411,11 @@ __global__ __launch_bounds__(NC / 8) void corr_kernel(CorrArgs a) {
         const cplx A = acc[2 * m];
         const cplx B = cconj(acc[2 * m + 1]);
         const cplx E = cscale(cadd(A, B), 0.5);
-        const cplx Op = cmul_conj(cscale(csub(A, B), 0.5), pm.w[m]);       // * exp(+2 pi i k/N)
+        const cplx Op = cmul_conj(cscale(csub(A, B), 0.5), pm.w(m));       // * exp(+2 pi i k/N)
         const cplx Zk = cadd(E, mul_posi(Op));
         const cplx Zm = cadd(cconj(E), mul_posi(cconj(Op)));
-        lds[pm.k[m]] = cconj(Zk);
-        if (!(tid == 0 && m == 0)) lds[NC - pm.k[m]] = cconj(Zm);
+        lds[pm.k(m)] = cconj(Zk);
+        if (!(tid == 0 && m == 0)) lds[NC - pm.k(m)] = cconj(Zm);
     }
     if (tid == 0) {
         const double E = 0.5 * (accDC + accNy), Op = 0.5 * (accDC - accNy);
@@ -371,7 +424,7 @@ __global__ __launch_bounds__(NC / 8) void corr_kernel(CorrArgs a) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = lds[tid + r * T];
-    fft_core<NC>(v, lds, a.t.tw, tid);
+    fft_core<NC>(v, lds, ft, tid);
     // z = conj(FFT(conj Z))/NC ; y[2n] = Re z, y[2n+1] = Im z  -> in place as doubles
     const double inv = 1.0 / (double)NC;
     for (int i = tid; i < NC; i += T) { const cplx z = lds[i]; lds[i] = cmk(z.x * inv, -z.y * inv); }
@@ -553,6 +606,8 @@ struct gf3_ctx {
     int *d_pos = nullptr, *d_clab = nullptr;
     double *d_cre = nullptr, *d_cim = nullptr;
     CorrPlan frames_plan, stream_plan;
+    int qpsk_fast = 0;
+    int contig_lo = 0;
     std::vector<double> chirp;
     mutable char err[512];
 };
@@ -590,19 +645,35 @@ static hipError_t launch(Kern k, int64_t grid, int threads, size_t lds, hipStrea
     return hipGetLastError();
 }
 
-#define DISPATCH_NC(NCv, CALL)                                  \
-    switch (NCv) {                                              \
-        case 512:  { constexpr int NCC = 512;  CALL; break; }   \
-        case 1024: { constexpr int NCC = 1024; CALL; break; }   \
-        case 2048: { constexpr int NCC = 2048; CALL; break; }   \
-        default:   { constexpr int NCC = 4096; CALL; break; }   \
+#ifdef GF3_DEV_BUILD   /* developer iteration: only N=4096 with f32/f64 samples */
+#define DISPATCH_DT(DTv, CALL)                                            \
+    switch (DTv) {                                                        \
+        case DT_F64: { constexpr int DTC = DT_F64; CALL; break; }         \
+        default:     { constexpr int DTC = DT_F32; CALL; break; }         \
     }
+#define DISPATCH_NC(NCv, DTv, CALL) { constexpr int NCC = 2048; DISPATCH_DT(DTv, CALL); }
+#else
+#define DISPATCH_DT(DTv, CALL)                                            \
+    switch (DTv) {                                                        \
+        case DT_F64: { constexpr int DTC = DT_F64; CALL; break; }         \
+        case DT_F32: { constexpr int DTC = DT_F32; CALL; break; }         \
+        case DT_I16: { constexpr int DTC = DT_I16; CALL; break; }         \
+        default:     { constexpr int DTC = DT_U8;  CALL; break; }         \
+    }
+#define DISPATCH_NC(NCv, DTv, CALL)                                       \
+    switch (NCv) {                                                        \
+        case 512:  { constexpr int NCC = 512;  DISPATCH_DT(DTv, CALL); break; }   \
+        case 1024: { constexpr int NCC = 1024; DISPATCH_DT(DTv, CALL); break; }   \
+        case 2048: { constexpr int NCC = 2048; DISPATCH_DT(DTv, CALL); break; }   \
+        default:   { constexpr int NCC = 4096; DISPATCH_DT(DTv, CALL); break; }   \
+    }
+#endif
 
 static hipError_t run_rfft(const gf3_ctx* c, const void* d_in, int64_t n_in, int dt, const int64_t* d_off,
                            int64_t n_sym, cplx* d_out, hipStream_t st) {
     RfftArgs a{{c->d_tw, c->d_twn}, d_in, n_in, d_off, dt, d_out};
     hipError_t e = hipSuccess;
-    DISPATCH_NC(c->NC, e = launch(rfft_kernel<NCC>, n_sym, NCC / 8, fft_lds_bytes(NCC), st, a));
+    DISPATCH_NC(c->NC, dt, e = launch((rfft_kernel<NCC, DTC>), n_sym, NCC / 8, fft_lds_bytes(NCC), st, a));
     return e;
 }
 
@@ -664,17 +735,35 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     const long double PI2 = 6.283185307179586476925286766559005768L;
     for (int m = 0; m < NC; ++m) { const long double a = -PI2 * m / NC; tw[m] = make_double2((double)cosl(a), (double)sinl(a)); }
     for (int k = 0; k <= NC / 2; ++k) { const long double a = -PI2 * k / N; twn[k] = make_double2((double)cosl(a), (double)sinl(a)); }
-    for (int k = 0; k < K; ++k) known[k] = make_double2(cfg->known_re[k], cfg->known_im[k]);
+    for (int k = 0; k < K; ++k) {                      // 1/known = conj(known)/|known|^2
+        const long double re = cfg->known_re[k], im = cfg->known_im[k], d = re * re + im * im;
+        known[k] = make_double2((double)(re / d), (double)(-im / d));
+    }
     std::vector<int> pos(K, -1), clab(cfg->M);
     for (int i = 0; i < cfg->C; ++i) {
         const int b = cfg->data_bins[i];
         if (b < 1 || b > K || pos[b - 1] != -1) { delete c; return fail(nullptr, GF3_EINVAL, "data_bins[%d]=%d invalid or repeated", i, b); }
         pos[b - 1] = i;
     }
+    {
+        bool contig = true;
+        for (int i = 1; i < cfg->C; ++i) contig = contig && cfg->data_bins[i] == cfg->data_bins[0] + i;
+        c->contig_lo = contig ? cfg->data_bins[0] : 0;
+    }
     for (int m = 0; m < cfg->M; ++m) {
         int lab = 0;
         for (int b = 0; b < cfg->mu; ++b) lab = (lab << 1) | (cfg->const_bits[m * cfg->mu + b] & 1);
         clab[m] = lab;
+    }
+    // the reference's QPSK table (OFDM.py:72-77): (+,+)00 (+,-)10 (-,-)11 (-,+)01 with |re|=|im|
+    if (cfg->M == 4 && cfg->mu == 2) {
+        const double q = cfg->const_re[0];
+        const double sr[4] = {1, 1, -1, -1}, si[4] = {1, -1, -1, 1};
+        const int labs[4] = {0, 2, 3, 1};
+        bool okq = q > 0.1 && q < 10.0;
+        for (int m = 0; m < 4; ++m)
+            okq = okq && cfg->const_re[m] == sr[m] * q && cfg->const_im[m] == si[m] * q && clab[m] == labs[m];
+        c->qpsk_fast = okq ? 1 : 0;
     }
     // chirp replica (sync_chirp, OFDM.py:106-109): linspace incl. endpoint, scipy linear chirp, /5
     c->chirp.resize(c->Lc);
@@ -746,12 +835,12 @@ extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, cons
     const gf3_config& g = c->cfg;
     DemodArgs a{{c->d_tw, c->d_twn}, d_in, n_in, d_off, g.in_dtype,
                 g.CP, c->S, g.P, g.D, c->K, g.C, g.mu, g.M,
-                c->d_known, c->d_pos, c->d_cre, c->d_cim, c->d_clab,
+                c->d_known, c->d_pos, c->contig_lo, c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, (cplx*)d_eq, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, d_status,
-                nullptr, nullptr, nullptr, nullptr};
+                nullptr, nullptr, nullptr, nullptr, c->qpsk_fast};
     hipError_t e = hipSuccess;
-    DISPATCH_NC(c->NC, e = launch((demod_kernel<NCC, false>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+    DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
     HIPCHK(c, e);
     return GF3_OK;
 }
@@ -764,12 +853,19 @@ extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start,
     const gf3_config& g = c->cfg;
     DemodArgs a{{c->d_tw, c->d_twn}, nullptr, 0, nullptr, g.in_dtype,
                 g.CP, c->S, g.P, g.D, c->K, g.C, g.mu, g.M,
-                c->d_known, c->d_pos, c->d_cre, c->d_cim, c->d_clab,
+                c->d_known, c->d_pos, c->contig_lo, c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, nullptr, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, nullptr,
-                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all};
+                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_fast};
     hipError_t e = hipSuccess;
-    DISPATCH_NC(c->NC, e = launch((demod_kernel<NCC, true>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+    switch (c->NC) {
+#ifndef GF3_DEV_BUILD
+        case 512:  e = launch((demod_kernel<512, DT_F64, true>), F, 64, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+        case 1024: e = launch((demod_kernel<1024, DT_F64, true>), F, 128, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+        case 4096: e = launch((demod_kernel<4096, DT_F64, true>), F, 512, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+#endif
+        default:   e = launch((demod_kernel<2048, DT_F64, true>), F, 256, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+    }
     HIPCHK(c, e);
     return GF3_OK;
 }
@@ -777,7 +873,7 @@ extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start,
 static hipError_t run_corr(const gf3_ctx* c, const CorrArgs& a, int64_t grid, hipStream_t st) {
     const size_t lds = fft_lds_bytes(c->NC) + 32 * sizeof(double);
     hipError_t e = hipSuccess;
-    DISPATCH_NC(c->NC, e = launch(corr_kernel<NCC>, grid, NCC / 8, lds, st, a));
+    DISPATCH_NC(c->NC, a.dt, e = launch((corr_kernel<NCC, DTC>), grid, NCC / 8, lds, st, a));
     return e;
 }
 

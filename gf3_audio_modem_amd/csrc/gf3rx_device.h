@@ -43,6 +43,27 @@ GF3_DEV cplx cdiv_np(cplx a, cplx b) {
 
 enum { DT_F64 = 0, DT_F32 = 1, DT_I16 = 2, DT_U8 = 3 };
 
+// Two consecutive samples as stored (one packed complex point), kept raw in
+// registers while in flight so that a prefetched symbol costs 8-32 VGPRs.
+// Sample offsets are arbitrary (sync decides them), so pair loads are only
+// element-aligned; gfx950 global loads accept that.
+template <int DT> struct RawT;
+template <> struct RawT<DT_F64> { typedef double E; };
+template <> struct RawT<DT_F32> { typedef float E; };
+template <> struct RawT<DT_I16> { typedef int16_t E; };
+template <> struct RawT<DT_U8>  { typedef uint8_t E; };
+template <int DT> struct RawPair {
+    typedef typename RawT<DT>::E E;
+    struct __attribute__((packed, aligned(sizeof(E)))) P2 { E a, b; };
+    P2 v;
+    GF3_DEV void load(const void* p, int64_t i) { v = *(const P2*)((const E*)p + i); }
+    GF3_DEV void zero() { v.a = 0; v.b = 0; }
+    GF3_DEV cplx get() const { return cmk((double)v.a, (double)v.b); }
+};
+template <int DT> GF3_DEV double load_sample_t(const void* p, int64_t i) {
+    return (double)((const typename RawT<DT>::E*)p)[i];
+}
+
 GF3_DEV double load_sample(const void* p, int64_t i, int dt) {
     switch (dt) {
         case DT_F64: return ((const double*)p)[i];
@@ -84,6 +105,22 @@ GF3_DEV void bfly8(cplx* v) {
 
 template <int R> GF3_DEV void bfly(cplx* v) { if constexpr (R == 8) bfly8(v); else bfly4(v); }
 
+// powers of a unit twiddle by multiplication (w^2..w^7): a few ulp, no table traffic
+template <int R> GF3_DEV void twiddle_mul(cplx* v, cplx w) {
+    const cplx w2 = cmul(w, w);
+    v[1] = cmul(v[1], w);
+    v[2] = cmul(v[2], w2);
+    const cplx w3 = cmul(w2, w);
+    v[3] = cmul(v[3], w3);
+    if constexpr (R == 8) {
+        const cplx w4 = cmul(w2, w2);
+        v[4] = cmul(v[4], w4);
+        v[5] = cmul(v[5], cmul(w4, w));
+        v[6] = cmul(v[6], cmul(w3, w3));
+        v[7] = cmul(v[7], cmul(w4, w3));
+    }
+}
+
 // ---------------------------------------------------------------- LDS FFT
 // LDS footprint of one FFT buffer, in cplx elements (first exchange is padded
 // by one element per 8 to break the stride-8 store conflict).
@@ -92,8 +129,15 @@ template <int NC> struct FftGeom {
     static constexpr int LDS_ELEMS = NC + NC / 8;
 };
 
+// Per-thread twiddle bases: the index k of every pass depends only on the thread,
+// so one unit twiddle per pass is loaded once per workgroup and kept in registers.
+template <int NC> struct FftTw {
+    cplx b2, b3, b4, c4;
+    GF3_DEV void init(int tid, const cplx* __restrict__ tw);
+};
+
 template <int NC, int R, int NS>
-GF3_DEV void fft_pass(cplx (&v)[8], cplx* lds, const cplx* __restrict__ tw, int tid) {
+GF3_DEV void fft_pass(cplx (&v)[8], cplx* lds, cplx wbase, cplx wstep, int tid) {
     constexpr int T = NC / 8, NB = 8 / R;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -106,8 +150,9 @@ GF3_DEV void fft_pass(cplx (&v)[8], cplx* lds, const cplx* __restrict__ tw, int 
     for (int b = 0; b < NB; ++b) {
         const int j = tid + b * T;
         const int k = j & (NS - 1);
-#pragma unroll
-        for (int r = 1; r < R; ++r) v[b * R + r] = cmul(v[b * R + r], tw[r * k * (NC / (NS * R))]);
+        cplx w = wbase;
+        if (b == 1 && NS > T) w = cmul(wbase, wstep);      // k advances by T for the second butterfly
+        twiddle_mul<R>(&v[b * R], w);
         bfly<R>(&v[b * R]);
         const int base = (j - k) * R + k;
 #pragma unroll
@@ -119,7 +164,7 @@ GF3_DEV void fft_pass(cplx (&v)[8], cplx* lds, const cplx* __restrict__ tw, int 
 // Forward complex FFT of NC points.  In: v[r] = z[tid + r*NC/8].  Out: Z[0..NC)
 // in natural order in lds[0..NC).  tw[m] = exp(-2 pi i m / NC).
 template <int NC>
-GF3_DEV void fft_core(cplx (&v)[8], cplx* lds, const cplx* __restrict__ tw, int tid) {
+GF3_DEV void fft_core(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid) {
     constexpr int T = NC / 8;
     bfly8(v);
     __syncthreads();                       // previous users of the buffer are done
@@ -131,8 +176,7 @@ GF3_DEV void fft_core(cplx (&v)[8], cplx* lds, const cplx* __restrict__ tw, int 
     __syncthreads();
     {
         const int k = tid & 7;
-#pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[r * k * (NC / 64)]);
+        twiddle_mul<8>(v, ft.b2);
         bfly8(v);
         const int base = (tid - k) * 8 + k;
 #pragma unroll
@@ -140,40 +184,59 @@ GF3_DEV void fft_core(cplx (&v)[8], cplx* lds, const cplx* __restrict__ tw, int 
     }
     __syncthreads();
     if constexpr (NC == 512) {
-        fft_pass<NC, 8, 64>(v, lds, tw, tid);
+        fft_pass<NC, 8, 64>(v, lds, ft.b3, ft.c4, tid);
     } else if constexpr (NC == 1024) {
-        fft_pass<NC, 4, 64>(v, lds, tw, tid);
-        fft_pass<NC, 4, 256>(v, lds, tw, tid);
+        fft_pass<NC, 4, 64>(v, lds, ft.b3, ft.c4, tid);
+        fft_pass<NC, 4, 256>(v, lds, ft.b4, ft.c4, tid);
     } else if constexpr (NC == 2048) {
-        fft_pass<NC, 8, 64>(v, lds, tw, tid);
-        fft_pass<NC, 4, 512>(v, lds, tw, tid);
+        fft_pass<NC, 8, 64>(v, lds, ft.b3, ft.c4, tid);
+        fft_pass<NC, 4, 512>(v, lds, ft.b4, ft.c4, tid);
     } else {
         static_assert(NC == 4096, "unsupported FFT size");
-        fft_pass<NC, 8, 64>(v, lds, tw, tid);
-        fft_pass<NC, 8, 512>(v, lds, tw, tid);
+        fft_pass<NC, 8, 64>(v, lds, ft.b3, ft.c4, tid);
+        fft_pass<NC, 8, 512>(v, lds, ft.b4, ft.c4, tid);
     }
 }
 
-// Bins owned by a thread after the FFT: slot 2m -> bin k[m] = tid + m*NC/8,
-// slot 2m+1 -> bin NC - k[m].  Thread 0's first pair would be (DC, Nyquist),
+template <int NC> GF3_DEV void FftTw<NC>::init(int tid, const cplx* __restrict__ tw) {
+    constexpr int T = NC / 8;
+    b2 = tw[(tid & 7) * (NC / 64)];                          // pass 2: radix 8, NS = 8
+    if constexpr (NC == 1024) {
+        b3 = tw[(tid & 63) * (NC / 256)];                    // radix 4, NS = 64
+        b4 = tw[(tid & 255) * (NC / 1024)];                  // radix 4, NS = 256 (k = tid + b*T)
+        c4 = tw[T * (NC / 1024)];
+    } else {
+        b3 = tw[(tid & 63) * (NC / 512)];                    // radix 8, NS = 64
+        if constexpr (NC == 2048) { b4 = tw[(tid & 511) * (NC / 2048)]; c4 = tw[T * (NC / 2048)]; }
+        else if constexpr (NC == 4096) { b4 = tw[(tid & 511) * (NC / 4096)]; c4 = cmk(1.0, 0.0); }
+        else { b4 = cmk(1.0, 0.0); c4 = cmk(1.0, 0.0); }
+    }
+}
+
+// Bins owned by a thread after the FFT: slot 2m -> bin k(m) = tid + m*NC/8,
+// slot 2m+1 -> bin NC - k(m).  Thread 0's first pair would be (DC, Nyquist),
 // which are not carriers; it owns the self-mirrored bin NC/2 there instead.
+// Only exp(-2 pi i tid / N) is kept; the other pair twiddles follow from it by
+// constant sixteenth-turn rotations (k advances by NC/8 = N/16 per m).
 template <int NC> struct PairMap {
-    int k[4];
-    cplx w[4];            // exp(-2 pi i k / (2 NC))
-    GF3_DEV void init(int tid, const cplx* __restrict__ twn) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            k[m] = tid + m * (NC / 8);
-            if (m == 0 && tid == 0) k[m] = NC / 2;
-            w[m] = twn[k[m]];
-        }
+    cplx wb;              // exp(-2 pi i tid / (2 NC))
+    int tid;
+    GF3_DEV void init(int t, const cplx* __restrict__ twn) { tid = t; wb = twn[t]; }
+    GF3_DEV int k(int m) const { return (m == 0 && tid == 0) ? NC / 2 : tid + m * (NC / 8); }
+    GF3_DEV cplx w(int m) const {
+        // exp(-2 pi i m / 16), m = 0..3
+        const cplx r16[4] = {cmk(1.0, 0.0), cmk(0.92387953251128675613, -0.38268343236508977173),
+                             cmk(GF3_SQRT1_2, -GF3_SQRT1_2), cmk(0.38268343236508977173, -0.92387953251128675613)};
+        if (m == 0) return tid == 0 ? cmk(0.0, -1.0) : wb;       // bin NC/2: exp(-i pi/2)
+        return cmul(wb, r16[m]);
     }
     // packed-real split: X[k], X[NC-k] of the 2NC-point real DFT from Z in LDS
     GF3_DEV void split(const cplx* lds, int m, cplx& Xk, cplx& Xm) const {
-        const cplx A = lds[k[m]];
-        const cplx B = cconj(lds[NC - k[m]]);
+        const int kk = k(m);
+        const cplx A = lds[kk];
+        const cplx B = cconj(lds[NC - kk]);
         const cplx E = cscale(cadd(A, B), 0.5);
-        const cplx O = cmul(mul_negi(cscale(csub(A, B), 0.5)), w[m]);
+        const cplx O = cmul(mul_negi(cscale(csub(A, B), 0.5)), w(m));
         Xk = cadd(E, O);
         Xm = cconj(csub(E, O));
     }
@@ -247,6 +310,31 @@ GF3_DEV void block_excl_scan2(double a, double b, double* scratch, double& ea, d
     ea = oa + (ia - a);
     eb = ob + (ib - b);
 }
+
+// sin/cos by Cody-Waite reduction to [-pi/4, pi/4] (three-part pi/2, exact with fma for
+// |x| < ~1e6) and the fdlibm kernel polynomials: <= 1 ulp there, ~30 fp64 ops.
+GF3_DEV void sincos_fast(double x, double& s, double& c) {
+    if (!(fabs(x) < 1.0e5)) { sincos(x, &s, &c); return; }
+    const double fn = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-fn, 1.57079632673412561417e+00, x);
+    r = fma(-fn, 6.07710050630396597660e-11, r);
+    r = fma(-fn, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                          2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
+                          -1.66666666666666324348e-01);
+    const double sr = fma(z * r, ps, r);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                          -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
+                          4.16666666666666019037e-02);
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)fn & 3;
+    s = (q & 1) ? cr : sr;
+    c = (q & 1) ? sr : cr;
+    if (q & 2) s = -s;
+    if ((q + 1) & 2) c = -c;
+}
+GF3_DEV cplx cis_fast(double x) { double s, c; sincos_fast(x, s, c); return cmk(c, s); }
 
 // np.unwrap's correction for one phase step dd = p[n] - p[n-1]
 GF3_DEV double unwrap_corr(double dd) {
