@@ -42,7 +42,7 @@ struct DemodArgs {
     const cplx* sp_start;     // [F, P, K]
     const cplx* sp_end;       // [F, P, K]
     cplx* eq_all;             // [F*D, K] equalised symbols on all carriers
-    int qpsk_fast;            // table is the reference QPSK table: decide by signs away from ties
+    double qpsk_q;            // >0: table is the reference QPSK table (+-q +-qj): decide by signs away from ties
 };
 
 // occupancy targets: min waves per SIMD handed to __launch_bounds__ (blocks of NC/8 threads).
@@ -108,18 +108,32 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void rfft_kernel(RfftArgs a) 
 // packet.  Symbols are processed start pilots -> end pilots -> data, the next
 // symbol's raw samples being fetched while the current one is transformed.
 // ============================================================================
-template <int NC, int DT, bool SPECTRA>
+// literal argmin scan over the reference QPSK table (+q,+q) (+q,-q) (-q,-q) (-q,+q) with
+// labels 00 10 11 01 (OFDM.py:72-77, 493-496); first minimum wins, branch-free
+GF3_DEV uint32_t qpsk_scan(cplx e, double q) {
+    const double xp = (e.x - q) * (e.x - q), xm = (e.x + q) * (e.x + q);
+    const double yp = (e.y - q) * (e.y - q), ym = (e.y + q) * (e.y + q);
+    double bd = xp + yp; uint32_t lab = 0u;
+    double d = xp + ym; if (d < bd) { bd = d; lab = 2u; }
+    d = xm + ym;        if (d < bd) { bd = d; lab = 3u; }
+    d = xm + yp;        if (d < bd) { bd = d; lab = 1u; }
+    return lab;
+}
+
+// FULL: also writes the per-symbol dumps (eq, eq_all, Hest); the lean variant produces only
+// the packed bits (+ the per-packet Hs/He/slope) and skips work decisions do not need.
+template <int NC, int DT, bool SPECTRA, bool FULL>
 __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a) {
     extern __shared__ double2 smem[];
     constexpr int T = NC / 8;
     cplx* lds = smem;
     double* scratch = (double*)(smem + FftGeom<NC>::LDS_ELEMS);           // 32 doubles
-    uint32_t* bitbuf = (uint32_t*)(scratch + 32);
+    cplx* rtab = (cplx*)(scratch + 32);                                   // [2][64 + NC/64 + 1] rotation tables
+    uint8_t* labs = (uint8_t*)(rtab + 2 * (64 + NC / 64 + 1));            // [2][C] decisions, one byte each
     const int tid = threadIdx.x;
     const int64_t f = blockIdx.x;
     const int K = a.K, P = a.P, D = a.D, S = a.S;
     const int Bs = a.C * a.mu;                                            // bits per data symbol
-    const int nwords = (Bs + 31) / 32 + 2;
     uint8_t* row = a.bits + f * (int64_t)a.row_bytes;
 
     int64_t off = 0;
@@ -138,8 +152,9 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
     // slot s = 2m+h: bin of the carrier it holds, whether it is a real slot, its data position
+    int tq = tid;                                     // re-laundered copy of tid, refreshed per symbol
     auto bin_of = [&](int s) { const int kk = pm.k(s >> 1); return (s & 1) ? NC - kk : kk; };
-    auto live_of = [&](int s) { return !(tid == 0 && s == 1); };          // thread 0, slot 1 repeats bin NC/2
+    auto live_of = [&](int s) { return !(tq == 0 && s == 1); };           // thread 0, slot 1 repeats bin NC/2
     auto pos_of = [&](int s) {
         if (!live_of(s)) return -1;
         const int bn = bin_of(s);
@@ -151,9 +166,9 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
     auto sym_pos = [&](int i) { return i < P ? i : (i < 2 * P ? D + i : i - P); };
     RawPair<DT> nxt[8];
     auto fetch = [&](int i) {
-        const int64_t s0 = off + (int64_t)sym_pos(i) * S + a.CP;
+        const int64_t s0 = off + (int64_t)sym_pos(i) * S + a.CP + 2 * launder(tid);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) nxt[r].load(a.in, s0 + 2 * (int64_t)(tid + r * T));
+        for (int r = 0; r < 8; ++r) nxt[r].load(a.in, s0 + 2 * (int64_t)(r * T));
     };
     const int Msym = 2 * P + D;
     cplx v[8];
@@ -161,7 +176,9 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (i + 1 < Msym) fetch(i + 1);
-        fft_core<NC>(v, lds, ft, tid);
+        fft_core<NC>(v, lds, ft, launder(tid));
+        tq = launder(tid);
+        pm.reseat(tq);
     };
     if constexpr (!SPECTRA) fetch(0);
 
@@ -241,24 +258,65 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
     }
     if (tid == 0 && a.slope) a.slope[f] = slope;
 
-    for (int i = tid; i < nwords; i += T) bitbuf[i] = 0;
-    // (fft_core's first barrier also orders this zeroing before the atomics)
-
     // ---- data symbols: FFT -> /Hest -> demap -> bit-pack (OFDM.py:466-478, 487-505)
+    // Decisions are staged as one byte per data carrier in a two-symbol LDS ring and
+    // packed into output words one symbol later (after the next FFT's barriers), so the
+    // packing needs no atomics and no barrier of its own.
+    const int C = a.C, mu = a.mu;
+    auto pack_words = [&](int l, bool tail) {
+        const int wlo = (l * Bs) >> 5, whi = ((l + 1) * Bs) >> 5;
+        const int nlab = D * C;                                            // labels in the packet
+        for (int w = wlo + launder(tid); w < whi + (tail ? 1 : 0); w += T) {
+            int i = (32 * w) / mu;                                         // first label touching the word
+            const int skip = 32 * w - i * mu;
+            int r = i % (2 * C);
+            uint64_t acc = 0;
+            int nb = 0;
+            while (nb < skip + 32) {
+                const uint32_t lb = (i < nlab) ? labs[r] : 0u;
+                acc = (acc << mu) | lb;
+                nb += mu; ++i;
+                if (++r == 2 * C) r = 0;
+            }
+            const uint32_t x = (uint32_t)(acc >> (nb - skip - 32));
+            if (w < whi) {
+                if ((a.row_bytes & 3) == 0) ((uint32_t*)row)[w] = __builtin_bswap32(x);
+                else { row[4 * w] = x >> 24; row[4 * w + 1] = x >> 16; row[4 * w + 2] = x >> 8; row[4 * w + 3] = x; }
+            } else {                                                       // partial last word of the packet
+                const int rem = (D * Bs) & 31;
+                for (int bb = 0; bb < ((rem + 7) >> 3); ++bb) row[4 * w + bb] = (uint8_t)(x >> (24 - 8 * bb));
+            }
+        }
+    };
     const double denom = (double)(D + P);
+    const double qq = a.qpsk_q;
+    // two-level table of carrier-index rotations exp(j phi n), rebuilt per data symbol by the
+    // first 64+NC/64+1 threads:  n + 1 = 64 h + i  ->  rot(n) = TH[h] * TL[i],
+    // TL[i] = exp(j phi (i-1)), TH[h] = exp(j phi 64 h).  Double-buffered on l & 1.
+    constexpr int NTH = NC / 64 + 1;
+    auto build_rot = [&](int l) {
+        const double phi_l = slope * (((double)l + 0.5 * (double)P) / denom);
+        cplx* tb = rtab + (l & 1) * (64 + NTH);
+        for (int i = launder(tid); i < 64 + NTH; i += T)
+            tb[i] = cis_fast(phi_l * (double)(i < 64 ? i - 1 : 64 * (i - 64)));
+    };
+    auto rot_of = [&](const cplx* tb, int n) {
+        const int n1 = n + 1;
+        return cmul(tb[64 + (n1 >> 6)], tb[n1 & 63]);
+    };
     for (int l = 0; l < D; ++l) {
         const cplx* sp = nullptr;
+        build_rot(l);
         if constexpr (SPECTRA) { sp = a.sp_data + ((int64_t)f * D + l) * K; __syncthreads(); }
         else transform(2 * P + l);
+        if (l > 0) pack_words(l - 1, false);
         const double fl = ((double)l + 0.5 * (double)P) / denom;          // (l + P/2)/(D+P)
-        const double phi = slope * fl;                                     // phase per carrier index
-        // exp(j phi n): slots 2m have n = (tid-1) + mT, slots 2m+1 have n = (NC-1-tid) - mT
-        cplx rA = cis_fast(phi * (double)(tid - 1));
-        cplx rB = cis_fast(phi * (double)(NC - 1 - tid));
-        const cplx rC = cis_fast(phi * (double)T);
-        if (tid == 0) rA = cis_fast(phi * (double)(NC / 2 - 1));          // slot 0 of thread 0 is bin NC/2 ...
-        const cplx rA1 = cis_fast(phi * (double)(T - 1));                  // ... and it rejoins the pattern at m = 1
-        const int w0 = (l * Bs) >> 5;
+        const cplx* tb = rtab + (l & 1) * (64 + NTH);
+        // slots 2m hold n = (tid-1) + mT (thread 0, m=0: n = NC/2-1); slots 2m+1 hold n = (NC-1-tid) - mT
+        cplx rA = rot_of(tb, bin_of(0) - 1);
+        cplx rB = rot_of(tb, NC - 1 - tq);
+        const cplx rC = tb[64 + T / 64];                                   // exp(j phi T)
+        uint8_t* lab_l = labs + (l & 1) * C;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             cplx X[2];
@@ -267,66 +325,50 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int s = 2 * m + h;
-                const int n = bin_of(s) - 1;
-                const bool live = live_of(s);
                 const double mag = fma(da[s], fl, a0[s]);
                 const cplx g = cmul(u[s], h ? rB : rA);                    // unit phasor of Hest
-                const double inv = 1.0 / mag;
-                const cplx e = cscale(cmul_conj(X[h], g), inv);            // X / (mag g)
-                if (live && a.Hest) a.Hest[((int64_t)f * D + l) * K + n] = cscale(g, mag);
-                if (live && a.eq_all) a.eq_all[((int64_t)f * D + l) * K + n] = e;
+                const cplx ep = cmul_conj(X[h], g);                        // X / g  = e * mag
                 const int ps = pos_of(s);
-                if (ps >= 0) {
-                    if (a.eq) a.eq[((int64_t)f * D + l) * a.C + ps] = e;
-                    uint32_t lab;
-                    const bool easy = a.qpsk_fast &&
-                        (fmin(fabs(e.x), fabs(e.y)) > 1e-6 * (1.0 + e.x * e.x + e.y * e.y));
-                    if (easy) {
-                        lab = (e.y < 0.0 ? 2u : 0u) | (e.x < 0.0 ? 1u : 0u);
-                    } else {                                              // literal table scan (OFDM.py:493-496)
-                        int best = 0;
-                        double dx = e.x - a.cre[0], dy = e.y - a.cim[0];
-                        double bd = dx * dx + dy * dy;
-                        for (int c = 1; c < a.M; ++c) {
-                            dx = e.x - a.cre[c]; dy = e.y - a.cim[c];
-                            const double d = dx * dx + dy * dy;
-                            if (d < bd) { bd = d; best = c; }
-                        }
-                        lab = (uint32_t)a.clab[best];
+                if constexpr (FULL) {
+                    const int n = bin_of(s) - 1;
+                    const cplx e = cscale(ep, rcp_nr(mag));
+                    if (live_of(s)) {
+                        if (a.Hest) a.Hest[((int64_t)f * D + l) * K + n] = cscale(g, mag);
+                        if (a.eq_all) a.eq_all[((int64_t)f * D + l) * K + n] = e;
                     }
-                    const int o = (l * a.C + ps) * a.mu;
-                    const uint64_t val = (uint64_t)lab << (64 - a.mu - (o & 31));
-                    const int w = (o >> 5) - w0;
-                    atomicOr(&bitbuf[w], (uint32_t)(val >> 32));
-                    if ((uint32_t)val) atomicOr(&bitbuf[w + 1], (uint32_t)val);
+                    if (ps >= 0 && a.eq) a.eq[((int64_t)f * D + l) * C + ps] = e;
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (ps >= 0) {
+                    uint32_t lab;
+                    const double ax = fabs(ep.x), ay = fabs(ep.y);
+                    // mag > 0, so QPSK decisions are the signs of ep unless a component sits next to a boundary
+                    if (qq > 0.0 && fmin(ax, ay) > 1e-5 * fmax(fmax(ax, ay), mag)) {
+                        lab = (ep.y < 0.0 ? 2u : 0u) | (ep.x < 0.0 ? 1u : 0u);
+                    } else {
+                        const cplx e = cscale(ep, rcp_nr(mag));
+                        if (qq > 0.0) lab = qpsk_scan(e, qq);
+                        else {                                             // literal table scan (OFDM.py:493-496)
+                            int best = 0;
+                            double dx = e.x - a.cre[0], dy = e.y - a.cim[0];
+                            double bd = dx * dx + dy * dy;
+                            for (int c = 1; c < a.M; ++c) {
+                                dx = e.x - a.cre[c]; dy = e.y - a.cim[c];
+                                const double d = dx * dx + dy * dy;
+                                if (d < bd) { bd = d; best = c; }
+                            }
+                            lab = (uint32_t)a.clab[best];
+                        }
+                    }
+                    lab_l[ps] = (uint8_t)lab;
+                }
             }
-            // advance the carrier-index rotations to m+1
-            rA = (m == 0 && tid == 0) ? rA1 : cmul(rA, rC);
+            // carrier-index rotations for m+1 (thread 0 rejoins the first pattern at n = T-1)
+            rA = (m == 0 && tq == 0) ? rot_of(tb, T - 1) : cmul(rA, rC);
             rB = cmul_conj(rB, rC);
         }
-        __syncthreads();
-        // flush the words this symbol completed; carry the partial one
-        const int w1 = ((l + 1) * Bs) >> 5;
-        const bool last = (l == D - 1);
-        for (int w = w0 + tid; w < w1; w += T) {
-            const uint32_t x = bitbuf[w - w0];
-            if ((a.row_bytes & 3) == 0) ((uint32_t*)row)[w] = __builtin_bswap32(x);
-            else { row[4 * w] = x >> 24; row[4 * w + 1] = x >> 16; row[4 * w + 2] = x >> 8; row[4 * w + 3] = x; }
-        }
-        uint32_t carry = 0;
-        if (tid == 0) {
-            const int rem = ((l + 1) * Bs) & 31;
-            if (rem) carry = bitbuf[w1 - w0];
-            if (last && rem) {
-                const int nb = (rem + 7) >> 3;
-                for (int b = 0; b < nb; ++b) row[4 * w1 + b] = (uint8_t)(carry >> (24 - 8 * b));
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < nwords; i += T) bitbuf[i] = (i == 0) ? carry : 0u;
     }
+    __syncthreads();
+    pack_words(D - 1, ((D * Bs) & 31) != 0);
 }
 
 // ============================================================================
@@ -369,9 +411,10 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) 
     auto fetch = [&](int q) {
         const int64_t seg = s0 + (int64_t)q * a.Lp;
         const bool inside = seg >= 0 && seg + 2 * NC <= a.n_in;
+        const int tf = launder(tid);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int j = 2 * (tid + r * T);
+            const int j = 2 * (tf + r * T);
             if (inside && j + 1 < need) nxt[r].load(a.in, seg + j);
             else {
                 nxt[r].zero();
@@ -387,10 +430,11 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) 
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (q + 1 < a.Q) fetch(q + 1);
+        pm.reseat(launder(tid));
         cplx hq[8];
 #pragma unroll
         for (int m = 0; m < 4; ++m) { hq[2 * m] = Hq[pm.k(m)]; hq[2 * m + 1] = Hq[NC - pm.k(m)]; }
-        fft_core<NC>(v, lds, ft, tid);
+        fft_core<NC>(v, lds, ft, launder(tid));
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             cplx Xk, Xm;
@@ -606,7 +650,7 @@ struct gf3_ctx {
     int *d_pos = nullptr, *d_clab = nullptr;
     double *d_cre = nullptr, *d_cim = nullptr;
     CorrPlan frames_plan, stream_plan;
-    int qpsk_fast = 0;
+    double qpsk_q = 0.0;
     int contig_lo = 0;
     std::vector<double> chirp;
     mutable char err[512];
@@ -763,7 +807,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
         bool okq = q > 0.1 && q < 10.0;
         for (int m = 0; m < 4; ++m)
             okq = okq && cfg->const_re[m] == sr[m] * q && cfg->const_im[m] == si[m] * q && clab[m] == labs[m];
-        c->qpsk_fast = okq ? 1 : 0;
+        c->qpsk_q = okq ? q : 0.0;
     }
     // chirp replica (sync_chirp, OFDM.py:106-109): linspace incl. endpoint, scipy linear chirp, /5
     c->chirp.resize(c->Lc);
@@ -824,7 +868,8 @@ extern "C" int gf3_rfft_batch(gf3_ctx* c, const void* d_in, int64_t n_in, const 
 }
 
 static size_t demod_lds_bytes(const gf3_ctx* c) {
-    return fft_lds_bytes(c->NC) + 32 * sizeof(double) + (size_t)((c->cfg.C * c->cfg.mu + 31) / 32 + 2) * 4;
+    return fft_lds_bytes(c->NC) + 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) +
+           (size_t)((2 * c->cfg.C + 15) & ~15);
 }
 
 extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,
@@ -838,9 +883,13 @@ extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, cons
                 c->d_known, c->d_pos, c->contig_lo, c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, (cplx*)d_eq, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, d_status,
-                nullptr, nullptr, nullptr, nullptr, c->qpsk_fast};
+                nullptr, nullptr, nullptr, nullptr, c->qpsk_q};
     hipError_t e = hipSuccess;
-    DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+    if (d_eq || d_Hest) {
+        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, true>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+    } else {
+        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, false>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+    }
     HIPCHK(c, e);
     return GF3_OK;
 }
@@ -856,15 +905,15 @@ extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start,
                 c->d_known, c->d_pos, c->contig_lo, c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, nullptr, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, nullptr,
-                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_fast};
+                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_q};
     hipError_t e = hipSuccess;
     switch (c->NC) {
 #ifndef GF3_DEV_BUILD
-        case 512:  e = launch((demod_kernel<512, DT_F64, true>), F, 64, demod_lds_bytes(c), (hipStream_t)stream, a); break;
-        case 1024: e = launch((demod_kernel<1024, DT_F64, true>), F, 128, demod_lds_bytes(c), (hipStream_t)stream, a); break;
-        case 4096: e = launch((demod_kernel<4096, DT_F64, true>), F, 512, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+        case 512:  e = launch((demod_kernel<512, DT_F64, true, true>), F, 64, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+        case 1024: e = launch((demod_kernel<1024, DT_F64, true, true>), F, 128, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+        case 4096: e = launch((demod_kernel<4096, DT_F64, true, true>), F, 512, demod_lds_bytes(c), (hipStream_t)stream, a); break;
 #endif
-        default:   e = launch((demod_kernel<2048, DT_F64, true>), F, 256, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+        default:   e = launch((demod_kernel<2048, DT_F64, true, true>), F, 256, demod_lds_bytes(c), (hipStream_t)stream, a); break;
     }
     HIPCHK(c, e);
     return GF3_OK;

@@ -41,6 +41,10 @@ GF3_DEV cplx cdiv_np(cplx a, cplx b) {
     return cmk((a.x * rat + a.y) * scl, (a.y * rat - a.x) * scl);
 }
 
+// Opaque copy of a per-thread index.  Everything derived from the copy is recomputed where it
+// is used instead of being hoisted out of the symbol loop and kept live (or spilled) across it.
+GF3_DEV int launder(int x) { asm volatile("" : "+v"(x)); return x; }
+
 enum { DT_F64 = 0, DT_F32 = 1, DT_I16 = 2, DT_U8 = 3 };
 
 // Two consecutive samples as stored (one packed complex point), kept raw in
@@ -222,6 +226,7 @@ template <int NC> struct PairMap {
     cplx wb;              // exp(-2 pi i tid / (2 NC))
     int tid;
     GF3_DEV void init(int t, const cplx* __restrict__ twn) { tid = t; wb = twn[t]; }
+    GF3_DEV void reseat(int t) { tid = t; }
     GF3_DEV int k(int m) const { return (m == 0 && tid == 0) ? NC / 2 : tid + m * (NC / 8); }
     GF3_DEV cplx w(int m) const {
         // exp(-2 pi i m / 16), m = 0..3
@@ -333,6 +338,14 @@ GF3_DEV void sincos_fast(double x, double& s, double& c) {
     c = (q & 1) ? sr : cr;
     if (q & 2) s = -s;
     if ((q + 1) & 2) c = -c;
+}
+// 1/x: v_rcp_f64 seed + two Newton steps (full double precision for normal x)
+GF3_DEV double rcp_nr(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
 }
 GF3_DEV cplx cis_fast(double x) { double s, c; sincos_fast(x, s, c); return cmk(c, s); }
 
