@@ -72,10 +72,9 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void rfft_kernel(RfftArgs a) 
     const int64_t sym = blockIdx.x;
     const int64_t off = a.off[sym];
     cplx* out = a.out + sym * (int64_t)(NC + 1);
-    PairMap<NC> pm;
-    pm.init(tid, a.t.twn);
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
+    const cplx wb = a.t.twn[tid];
     cplx v[8];
     const bool ok = off >= 0 && off + 2 * NC <= a.n_in;
 #pragma unroll
@@ -84,16 +83,12 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void rfft_kernel(RfftArgs a) 
         if (ok) raw.load(a.in, off + 2 * (int64_t)(tid + r * T)); else raw.zero();
         v[r] = raw.get();
     }
-    fft_core<NC>(v, smem, ft, tid);
+    cplx z0;
+    rfft_regs<NC>(v, smem, ft, wb, tid, z0);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        cplx Xk, Xm;
-        pm.split(smem, m, Xk, Xm);
-        out[pm.k(m)] = Xk;
-        if (!(tid == 0 && m == 0)) out[NC - pm.k(m)] = Xm;
-    }
+    for (int s2 = 0; s2 < 8; ++s2)
+        if (Spec<NC>::live(tid, s2)) out[Spec<NC>::bin(tid, s2)] = v[s2];
     if (tid == 0) {
-        const cplx z0 = smem[0];
         out[0] = cmk(z0.x + z0.y, 0.0);
         out[NC] = cmk(z0.x - z0.y, 0.0);
     }
@@ -103,10 +98,10 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void rfft_kernel(RfftArgs a) 
 // fused demodulation of one packet per workgroup
 // (get_symbols..PS, OFDM.py:391-505; equalise :422-480 is the bulk)
 //
-// Per thread: 8 carriers ("slots": bins tid+m*T and NC-tid-m*T), whose channel
-// state (unit phasor of Hs, |Hs|, |He|-|Hs|) stays in registers for the whole
-// packet.  Symbols are processed start pilots -> end pilots -> data, the next
-// symbol's raw samples being fetched while the current one is transformed.
+// Per thread: 8 carriers ("slots", Spec<NC>), whose channel state (unit phasor of Hs,
+// |Hs|, |He|-|Hs|) stays in registers for the whole packet.  Symbols are processed
+// start pilots -> end pilots -> data, the next symbol's raw samples being fetched
+// while the current one is transformed.
 // ============================================================================
 // literal argmin scan over the reference QPSK table (+q,+q) (+q,-q) (-q,-q) (-q,+q) with
 // labels 00 10 11 01 (OFDM.py:72-77, 493-496); first minimum wins, branch-free
@@ -120,10 +115,27 @@ GF3_DEV uint32_t qpsk_scan(cplx e, double q) {
     return lab;
 }
 
-// FULL: also writes the per-symbol dumps (eq, eq_all, Hest); the lean variant produces only
-// the packed bits (+ the per-packet Hs/He/slope) and skips work decisions do not need.
-template <int NC, int DT, bool SPECTRA, bool FULL>
-__global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a) {
+// Decision of the literal scan above for exact arithmetic, from the signs of e (or of any
+// positive multiple of e): the scan's first-minimum rule breaks the four axis ties as
+// Re=0 -> Re>=0 side, Im=0 -> (Re<0 ? Im<0 side : Im>=0 side); NaN/Inf -> first point.
+GF3_DEV uint32_t qpsk_sign_rule(cplx e) {
+    const bool fin = (fabs(e.x) < INFINITY) && (fabs(e.y) < INFINITY);
+    const uint32_t b1 = e.x < 0.0 ? 1u : 0u;
+    const uint32_t b0 = (e.y < 0.0 || (e.y == 0.0 && e.x < 0.0)) ? 2u : 0u;
+    return fin ? (b0 | b1) : 0u;
+}
+
+// MODE_FULL : per-symbol dumps (eq, eq_all, Hest) + literal table scan on the equalised symbol
+// MODE_SCAN : bits only, any constellation: normalise and scan literally
+// MODE_QPSK : bits only, reference QPSK table.  The channel magnitude model
+//             (1-f)|Hs| + f|He| is positive, so X/Hest and X*conj(u*rot) have the same signs and
+//             the decision needs neither the division nor |Hs|, |He|: per-carrier state is u alone.
+enum { MODE_FULL = 0, MODE_SCAN = 1, MODE_QPSK = 2 };
+template <int NC, int MODE> struct DemodOcc { static constexpr int WPS = 2; };
+
+template <int NC, int DT, bool SPECTRA, int MODE>
+__global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kernel(DemodArgs a) {
+    constexpr bool FULL = (MODE == MODE_FULL);
     extern __shared__ double2 smem[];
     constexpr int T = NC / 8;
     cplx* lds = smem;
@@ -147,14 +159,12 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
         }
     }
 
-    PairMap<NC> pm;
-    pm.init(tid, a.t.twn);
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
-    // slot s = 2m+h: bin of the carrier it holds, whether it is a real slot, its data position
+    const cplx wb = a.t.twn[tid];
     int tq = tid;                                     // re-laundered copy of tid, refreshed per symbol
-    auto bin_of = [&](int s) { const int kk = pm.k(s >> 1); return (s & 1) ? NC - kk : kk; };
-    auto live_of = [&](int s) { return !(tq == 0 && s == 1); };           // thread 0, slot 1 repeats bin NC/2
+    auto bin_of = [&](int s) { return Spec<NC>::bin(tq, s); };
+    auto live_of = [&](int s) { return Spec<NC>::live(tq, s); };
     auto pos_of = [&](int s) {
         if (!live_of(s)) return -1;
         const int bn = bin_of(s);
@@ -171,14 +181,18 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
         for (int r = 0; r < 8; ++r) nxt[r].load(a.in, s0 + 2 * (int64_t)(r * T));
     };
     const int Msym = 2 * P + D;
-    cplx v[8];
-    auto transform = [&](int i) {                     // nxt -> spectrum Z in LDS; prefetch i+1
+    cplx v[8], z0;
+    auto transform = [&](int i) {                     // nxt -> spectrum slots in v; prefetch i+1
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (i + 1 < Msym) fetch(i + 1);
-        fft_core<NC>(v, lds, ft, launder(tid));
         tq = launder(tid);
-        pm.reseat(tq);
+        rfft_regs<NC>(v, lds, ft, wb, tq, z0);
+    };
+    auto load_spectra = [&](const cplx* sp) {         // SPECTRA mode: slots straight from memory
+        tq = launder(tid);
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) v[s2] = sp[bin_of(s2) - 1];
     };
     if constexpr (!SPECTRA) fetch(0);
 
@@ -188,44 +202,46 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
     for (int s = 0; s < 8; ++s) Hs[s] = He[s] = cmk(0.0, 0.0);
     for (int i = 0; i < 2 * P; ++i) {
         const bool side = i >= P;
-        const cplx* sp = nullptr;
-        if constexpr (SPECTRA) sp = (side ? a.sp_end : a.sp_start) + ((int64_t)f * P + (side ? i - P : i)) * K;
+        if constexpr (SPECTRA) load_spectra((side ? a.sp_end : a.sp_start) + ((int64_t)f * P + (side ? i - P : i)) * K);
         else transform(i);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            cplx Xk, Xm;
-            if constexpr (SPECTRA) { Xk = sp[bin_of(2 * m) - 1]; Xm = sp[bin_of(2 * m + 1) - 1]; }
-            else pm.split(lds, m, Xk, Xm);
-            if (side) { He[2 * m] = cadd(He[2 * m], Xk); He[2 * m + 1] = cadd(He[2 * m + 1], Xm); }
-            else      { Hs[2 * m] = cadd(Hs[2 * m], Xk); Hs[2 * m + 1] = cadd(Hs[2 * m + 1], Xm); }
+        for (int s2 = 0; s2 < 8; ++s2) {
+            if (side) He[s2] = cadd(He[s2], v[s2]); else Hs[s2] = cadd(Hs[s2], v[s2]);
         }
     }
 
-    // ---- per carrier: H = mean / known; phases to LDS; equaliser state
+    // ---- per carrier: H = mean / known; equaliser state
     //      Hest = (a0 + da f_l) u exp(j slope n f_l),  u = Hs/|Hs| = exp(j angle(Hs))
-    __syncthreads();                                  // all reads of Z done; reuse the buffer
+    // Only the carriers inside the fit range need their angles: unwrap corrections before
+    // fit_lo shift every fitted point by the same constant, which a slope does not see.
+    __syncthreads();                                  // FFT buffer is free: reuse it for the phases
     double* ph0 = (double*)lds;
     double* ph1 = ph0 + NC;
     cplx u[8];
     double a0[8], da[8];
-    const double dP = (double)P;
+    const double invP = 1.0 / (double)P;
+    tq = launder(tid);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int bn = bin_of(s);
         const cplx ik = a.inv_known[bn - 1];
-        const cplx hs = cmul(cmk(Hs[s].x / dP, Hs[s].y / dP), ik);
-        const cplx he = cmul(cmk(He[s].x / dP, He[s].y / dP), ik);
+        const cplx hs = cmul(cscale(Hs[s], invP), ik);
+        const cplx he = cmul(cscale(He[s], invP), ik);
         if (live_of(s)) {
             if (a.Hs) a.Hs[f * K + bn - 1] = hs;
             if (a.He) a.He[f * K + bn - 1] = he;
-            ph0[bn - 1] = atan2(hs.y, hs.x);
-            ph1[bn - 1] = atan2(he.y, he.x);
+            if (bn - 1 >= a.fit_lo && bn - 1 < a.fit_hi) {
+                ph0[bn - 1] = atan2(hs.y, hs.x);
+                ph1[bn - 1] = atan2(he.y, he.x);
+            }
         }
-        a0[s] = sqrt(hs.x * hs.x + hs.y * hs.y);
-        da[s] = sqrt(he.x * he.x + he.y * he.y) - a0[s];
-        const double ia = 1.0 / a0[s];
+        const double ahs = sqrt(hs.x * hs.x + hs.y * hs.y);
+        if constexpr (MODE != MODE_QPSK) {
+            a0[s] = ahs;
+            da[s] = sqrt(he.x * he.x + he.y * he.y) - ahs;
+        }
+        const double ia = rcp_nr(ahs);
         u[s] = cmk(hs.x * ia, hs.y * ia);
-        __builtin_amdgcn_sched_barrier(0);            // one carrier at a time: keeps live ranges short
     }
     __syncthreads();
 
@@ -234,10 +250,11 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
     {
         const int n0 = tid * 8;
         double c0[8], c1[8], r0 = 0.0, r1 = 0.0;
+        const bool touch = n0 + 8 > a.fit_lo && n0 < a.fit_hi;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int n = n0 + i;
-            if (n >= 1 && n < K) {
+            if (touch && n > a.fit_lo && n < a.fit_hi) {
                 r0 += unwrap_corr(ph0[n] - ph0[n - 1]);
                 r1 += unwrap_corr(ph1[n] - ph1[n - 1]);
             }
@@ -246,12 +263,14 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
         double e0, e1;
         block_excl_scan2(r0, r1, scratch, e0, e1);
         double acc = 0.0;
+        if (touch) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = n0 + i;
-            if (n >= a.fit_lo && n < a.fit_hi) {
-                const double y = (ph1[n] + (e1 + c1[i])) - (ph0[n] + (e0 + c0[i]));
-                acc += y * ((double)(n - a.fit_lo) - a.xbar);
+            for (int i = 0; i < 8; ++i) {
+                const int n = n0 + i;
+                if (n >= a.fit_lo && n < a.fit_hi) {
+                    const double y = (ph1[n] + (e1 + c1[i])) - (ph0[n] + (e0 + c0[i]));
+                    acc += y * ((double)(n - a.fit_lo) - a.xbar);
+                }
             }
         }
         slope = block_sum(acc, scratch + 16) * a.inv_sxx;
@@ -305,33 +324,25 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
         return cmul(tb[64 + (n1 >> 6)], tb[n1 & 63]);
     };
     for (int l = 0; l < D; ++l) {
-        const cplx* sp = nullptr;
         build_rot(l);
-        if constexpr (SPECTRA) { sp = a.sp_data + ((int64_t)f * D + l) * K; __syncthreads(); }
+        if constexpr (SPECTRA) { __syncthreads(); load_spectra(a.sp_data + ((int64_t)f * D + l) * K); }
         else transform(2 * P + l);
         if (l > 0) pack_words(l - 1, false);
         const double fl = ((double)l + 0.5 * (double)P) / denom;          // (l + P/2)/(D+P)
         const cplx* tb = rtab + (l & 1) * (64 + NTH);
-        // slots 2m hold n = (tid-1) + mT (thread 0, m=0: n = NC/2-1); slots 2m+1 hold n = (NC-1-tid) - mT
-        cplx rA = rot_of(tb, bin_of(0) - 1);
-        cplx rB = rot_of(tb, NC - 1 - tq);
-        const cplx rC = tb[64 + T / 64];                                   // exp(j phi T)
         uint8_t* lab_l = labs + (l & 1) * C;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            cplx X[2];
-            if constexpr (SPECTRA) { X[0] = sp[bin_of(2 * m) - 1]; X[1] = sp[bin_of(2 * m + 1) - 1]; }
-            else pm.split(lds, m, X[0], X[1]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int s = 2 * m + h;
+        for (int s = 0; s < 8; ++s) {
+            const int n = bin_of(s) - 1;
+            const cplx g = cmul(u[s], rot_of(tb, n));                      // unit phasor of Hest
+            const cplx ep = cmul_conj(v[s], g);                            // X / g  = e * mag
+            const int ps = pos_of(s);
+            if constexpr (MODE == MODE_QPSK) {
+                if (ps >= 0) lab_l[ps] = (uint8_t)qpsk_sign_rule(ep);
+            } else {
                 const double mag = fma(da[s], fl, a0[s]);
-                const cplx g = cmul(u[s], h ? rB : rA);                    // unit phasor of Hest
-                const cplx ep = cmul_conj(X[h], g);                        // X / g  = e * mag
-                const int ps = pos_of(s);
+                const cplx e = cscale(ep, rcp_nr(mag));
                 if constexpr (FULL) {
-                    const int n = bin_of(s) - 1;
-                    const cplx e = cscale(ep, rcp_nr(mag));
                     if (live_of(s)) {
                         if (a.Hest) a.Hest[((int64_t)f * D + l) * K + n] = cscale(g, mag);
                         if (a.eq_all) a.eq_all[((int64_t)f * D + l) * K + n] = e;
@@ -340,31 +351,21 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void demod_kernel(DemodArgs a
                 }
                 if (ps >= 0) {
                     uint32_t lab;
-                    const double ax = fabs(ep.x), ay = fabs(ep.y);
-                    // mag > 0, so QPSK decisions are the signs of ep unless a component sits next to a boundary
-                    if (qq > 0.0 && fmin(ax, ay) > 1e-5 * fmax(fmax(ax, ay), mag)) {
-                        lab = (ep.y < 0.0 ? 2u : 0u) | (ep.x < 0.0 ? 1u : 0u);
-                    } else {
-                        const cplx e = cscale(ep, rcp_nr(mag));
-                        if (qq > 0.0) lab = qpsk_scan(e, qq);
-                        else {                                             // literal table scan (OFDM.py:493-496)
-                            int best = 0;
-                            double dx = e.x - a.cre[0], dy = e.y - a.cim[0];
-                            double bd = dx * dx + dy * dy;
-                            for (int c = 1; c < a.M; ++c) {
-                                dx = e.x - a.cre[c]; dy = e.y - a.cim[c];
-                                const double d = dx * dx + dy * dy;
-                                if (d < bd) { bd = d; best = c; }
-                            }
-                            lab = (uint32_t)a.clab[best];
+                    if (qq > 0.0) lab = qpsk_scan(e, qq);
+                    else {                                                 // literal table scan (OFDM.py:493-496)
+                        int best = 0;
+                        double dx = e.x - a.cre[0], dy = e.y - a.cim[0];
+                        double bd = dx * dx + dy * dy;
+                        for (int c = 1; c < a.M; ++c) {
+                            dx = e.x - a.cre[c]; dy = e.y - a.cim[c];
+                            const double d = dx * dx + dy * dy;
+                            if (d < bd) { bd = d; best = c; }
                         }
+                        lab = (uint32_t)a.clab[best];
                     }
                     lab_l[ps] = (uint8_t)lab;
                 }
             }
-            // carrier-index rotations for m+1 (thread 0 rejoins the first pattern at n = T-1)
-            rA = (m == 0 && tq == 0) ? rot_of(tb, T - 1) : cmul(rA, rC);
-            rB = cmul_conj(rB, rC);
         }
     }
     __syncthreads();
@@ -397,10 +398,9 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) 
         W = left < a.V ? (int)left : a.V;
     }
 
-    PairMap<NC> pm;
-    pm.init(tid, a.t.twn);
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
+    const cplx wb = a.t.twn[tid];
     cplx acc[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc[s] = cmk(0.0, 0.0);
@@ -424,42 +424,40 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) 
         }
     };
     fetch(0);
-    cplx v[8];
+    cplx v[8], z0;
     for (int q = 0; q < a.Q; ++q) {
         const cplx* Hq = a.Hq + (int64_t)q * (NC + 1);
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (q + 1 < a.Q) fetch(q + 1);
-        pm.reseat(launder(tid));
+        const int tq = launder(tid);
         cplx hq[8];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { hq[2 * m] = Hq[pm.k(m)]; hq[2 * m + 1] = Hq[NC - pm.k(m)]; }
-        fft_core<NC>(v, lds, ft, launder(tid));
+        for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec<NC>::bin(tq, s)];
+        rfft_regs<NC>(v, lds, ft, wb, tq, z0);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            cplx Xk, Xm;
-            pm.split(lds, m, Xk, Xm);
-            acc[2 * m] = cadd(acc[2 * m], cmul_conj(Xk, hq[2 * m]));
-            acc[2 * m + 1] = cadd(acc[2 * m + 1], cmul_conj(Xm, hq[2 * m + 1]));
-        }
+        for (int s = 0; s < 8; ++s) acc[s] = cadd(acc[s], cmul_conj(v[s], hq[s]));
         if (tid == 0) {
-            const cplx z0 = lds[0];
             accDC += (z0.x + z0.y) * Hq[0].x;
             accNy += (z0.x - z0.y) * Hq[NC].x;
         }
     }
     // ---- inverse real FFT of the accumulated Hermitian spectrum Y
     __syncthreads();
+    {
+        const int tq = launder(tid);
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const cplx A = acc[2 * m];
-        const cplx B = cconj(acc[2 * m + 1]);
-        const cplx E = cscale(cadd(A, B), 0.5);
-        const cplx Op = cmul_conj(cscale(csub(A, B), 0.5), pm.w(m));       // * exp(+2 pi i k/N)
-        const cplx Zk = cadd(E, mul_posi(Op));
-        const cplx Zm = cadd(cconj(E), mul_posi(cconj(Op)));
-        lds[pm.k(m)] = cconj(Zk);
-        if (!(tid == 0 && m == 0)) lds[NC - pm.k(m)] = cconj(Zm);
+        for (int r = 0; r < 4; ++r) {
+            const int k = Spec<NC>::bin(tq, 2 * r);
+            const cplx A = acc[2 * r];
+            const cplx B = cconj(acc[2 * r + 1]);
+            const cplx E = cscale(cadd(A, B), 0.5);
+            const cplx Op = cmul_conj(cscale(csub(A, B), 0.5), Spec<NC>::pair_tw(tq, r, wb));   // * exp(+2 pi i k/N)
+            const cplx Zk = cadd(E, mul_posi(Op));
+            const cplx Zm = cadd(cconj(E), mul_posi(cconj(Op)));
+            lds[k] = cconj(Zk);
+            if (Spec<NC>::live(tq, 2 * r + 1)) lds[NC - k] = cconj(Zm);
+        }
     }
     if (tid == 0) {
         const double E = 0.5 * (accDC + accNy), Op = 0.5 * (accDC - accNy);
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) 
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = lds[tid + r * T];
-    fft_core<NC>(v, lds, ft, tid);
+    fft_core<NC>(v, lds, ft, launder(tid));
     // z = conj(FFT(conj Z))/NC ; y[2n] = Re z, y[2n+1] = Im z  -> in place as doubles
     const double inv = 1.0 / (double)NC;
     for (int i = tid; i < NC; i += T) { const cplx z = lds[i]; lds[i] = cmk(z.x * inv, -z.y * inv); }
@@ -886,9 +884,11 @@ extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, cons
                 nullptr, nullptr, nullptr, nullptr, c->qpsk_q};
     hipError_t e = hipSuccess;
     if (d_eq || d_Hest) {
-        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, true>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_FULL>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+    } else if (c->qpsk_q > 0.0) {
+        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_QPSK>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
     } else {
-        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, false>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_SCAN>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
     }
     HIPCHK(c, e);
     return GF3_OK;
@@ -909,11 +909,11 @@ extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start,
     hipError_t e = hipSuccess;
     switch (c->NC) {
 #ifndef GF3_DEV_BUILD
-        case 512:  e = launch((demod_kernel<512, DT_F64, true, true>), F, 64, demod_lds_bytes(c), (hipStream_t)stream, a); break;
-        case 1024: e = launch((demod_kernel<1024, DT_F64, true, true>), F, 128, demod_lds_bytes(c), (hipStream_t)stream, a); break;
-        case 4096: e = launch((demod_kernel<4096, DT_F64, true, true>), F, 512, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+        case 512:  e = launch((demod_kernel<512, DT_F64, true, MODE_FULL>), F, 64, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+        case 1024: e = launch((demod_kernel<1024, DT_F64, true, MODE_FULL>), F, 128, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+        case 4096: e = launch((demod_kernel<4096, DT_F64, true, MODE_FULL>), F, 512, demod_lds_bytes(c), (hipStream_t)stream, a); break;
 #endif
-        default:   e = launch((demod_kernel<2048, DT_F64, true, true>), F, 256, demod_lds_bytes(c), (hipStream_t)stream, a); break;
+        default:   e = launch((demod_kernel<2048, DT_F64, true, MODE_FULL>), F, 256, demod_lds_bytes(c), (hipStream_t)stream, a); break;
     }
     HIPCHK(c, e);
     return GF3_OK;

@@ -136,7 +136,8 @@ template <int NC> struct FftGeom {
 // Per-thread twiddle bases: the index k of every pass depends only on the thread,
 // so one unit twiddle per pass is loaded once per workgroup and kept in registers.
 template <int NC> struct FftTw {
-    cplx b2, b3, b4, c4;
+    cplx b2, b3, b4, c4;      // c4: step to the second butterfly of a 2-butterfly pass, or (fused
+                              // sizes) the base twiddle of the mirrored butterfly of the last pass
     GF3_DEV void init(int tid, const cplx* __restrict__ tw);
 };
 
@@ -165,10 +166,62 @@ GF3_DEV void fft_pass(cplx (&v)[8], cplx* lds, cplx wbase, cplx wstep, int tid) 
     __syncthreads();
 }
 
-// Forward complex FFT of NC points.  In: v[r] = z[tid + r*NC/8].  Out: Z[0..NC)
-// in natural order in lds[0..NC).  tw[m] = exp(-2 pi i m / NC).
-template <int NC>
-GF3_DEV void fft_core(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid) {
+// Slot layout of one real-FFT result held in registers: thread t owns 8 bins,
+// slot s = 2r + h  ->  h = 0: bin k_r,  h = 1: bin NC - k_r  (a mirrored pair per r).
+//   fused sizes (NC = 1024, 2048: last pass is radix 4 with two butterflies per thread):
+//       k_r = t + r*NC/4;   thread 0 (whose butterflies mirror onto themselves): NC/2, NC/4, NC/8, 3NC/8
+//   other sizes: k_r = t + r*NC/8; thread 0, r = 0: NC/2
+// Thread 0's slot 1 repeats bin NC/2 and is not "live".  DC/Nyquist come back separately (z0).
+template <int NC> struct Spec {
+    static constexpr bool FUSED = (NC == 1024 || NC == 2048);
+    static constexpr int Q = NC / 4, T = NC / 8;
+    GF3_DEV static int bin(int t, int s) {
+        const int r = s >> 1;
+        int k;
+        if constexpr (FUSED) {
+            const int k0 = (r == 0) ? NC / 2 : (r == 1 ? Q : (r == 2 ? Q / 2 : 3 * Q / 2));
+            k = (t == 0) ? k0 : t + r * Q;
+        } else {
+            k = (t == 0 && r == 0) ? NC / 2 : t + r * T;
+        }
+        return (s & 1) ? NC - k : k;
+    }
+    GF3_DEV static bool live(int t, int s) { return !(t == 0 && s == 1); }
+    // exp(-2 pi i k_r / N), N = 2 NC, from wb = exp(-2 pi i t / N)
+    GF3_DEV static cplx pair_tw(int t, int r, cplx wb) {
+        const double c8 = 0.92387953251128675613, s8 = 0.38268343236508977173;
+        if constexpr (FUSED) {          // k advances by N/8 per r
+            cplx w = wb;
+            if (r == 1) w = cmk((wb.x + wb.y) * GF3_SQRT1_2, (wb.y - wb.x) * GF3_SQRT1_2);
+            if (r == 2) w = mul_negi(wb);
+            if (r == 3) w = cmk((wb.y - wb.x) * GF3_SQRT1_2, -(wb.x + wb.y) * GF3_SQRT1_2);
+            if (t == 0) {
+                if (r == 0) w = cmk(0.0, -1.0);
+                if (r == 2) w = cmk(c8, -s8);
+                if (r == 3) w = cmk(s8, -c8);
+            }
+            return w;
+        } else {                        // k advances by N/16 per r
+            const cplx r16[4] = {cmk(1.0, 0.0), cmk(c8, -s8), cmk(GF3_SQRT1_2, -GF3_SQRT1_2), cmk(s8, -c8)};
+            if (r == 0) return t == 0 ? cmk(0.0, -1.0) : wb;
+            return cmul(wb, r16[r]);
+        }
+    }
+};
+
+// packed-real split of one mirrored pair: A = Z[k], Bm = Z[NC-k], w = exp(-2 pi i k / N)
+GF3_DEV void real_split(cplx A, cplx Bm, cplx w, cplx& Xk, cplx& Xm) {
+    const cplx B = cconj(Bm);
+    const cplx E = cscale(cadd(A, B), 0.5);
+    const cplx O = cmul(mul_negi(cscale(csub(A, B), 0.5)), w);
+    Xk = cadd(E, O);
+    Xm = cconj(csub(E, O));
+}
+
+// passes 1..2 (radix 8) and, where there are four passes, pass 3; leaves the Stockham
+// intermediate in LDS.  In: v[r] = z[tid + r*NC/8].
+template <int NC, bool ALL>
+GF3_DEV void fft_passes(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid) {
     constexpr int T = NC / 8;
     bfly8(v);
     __syncthreads();                       // previous users of the buffer are done
@@ -187,65 +240,74 @@ GF3_DEV void fft_core(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid) {
         for (int r = 0; r < 8; ++r) lds[base + r * 8] = v[r];
     }
     __syncthreads();
+    const cplx w8 = cmk(GF3_SQRT1_2, -GF3_SQRT1_2);              // exp(-i pi/4): T steps of the last pass
     if constexpr (NC == 512) {
-        fft_pass<NC, 8, 64>(v, lds, ft.b3, ft.c4, tid);
+        fft_pass<NC, 8, 64>(v, lds, ft.b3, w8, tid);
     } else if constexpr (NC == 1024) {
-        fft_pass<NC, 4, 64>(v, lds, ft.b3, ft.c4, tid);
-        fft_pass<NC, 4, 256>(v, lds, ft.b4, ft.c4, tid);
+        fft_pass<NC, 4, 64>(v, lds, ft.b3, w8, tid);
+        if constexpr (ALL) fft_pass<NC, 4, 256>(v, lds, ft.b4, w8, tid);
     } else if constexpr (NC == 2048) {
-        fft_pass<NC, 8, 64>(v, lds, ft.b3, ft.c4, tid);
-        fft_pass<NC, 4, 512>(v, lds, ft.b4, ft.c4, tid);
+        fft_pass<NC, 8, 64>(v, lds, ft.b3, w8, tid);
+        if constexpr (ALL) fft_pass<NC, 4, 512>(v, lds, ft.b4, w8, tid);
     } else {
         static_assert(NC == 4096, "unsupported FFT size");
-        fft_pass<NC, 8, 64>(v, lds, ft.b3, ft.c4, tid);
-        fft_pass<NC, 8, 512>(v, lds, ft.b4, ft.c4, tid);
+        fft_pass<NC, 8, 64>(v, lds, ft.b3, w8, tid);
+        fft_pass<NC, 8, 512>(v, lds, ft.b4, w8, tid);
     }
+}
+
+// Forward complex FFT of NC points, result Z[0..NC) in natural order in lds[0..NC).
+template <int NC>
+GF3_DEV void fft_core(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid) {
+    fft_passes<NC, true>(v, lds, ft, tid);
 }
 
 template <int NC> GF3_DEV void FftTw<NC>::init(int tid, const cplx* __restrict__ tw) {
-    constexpr int T = NC / 8;
     b2 = tw[(tid & 7) * (NC / 64)];                          // pass 2: radix 8, NS = 8
-    if constexpr (NC == 1024) {
-        b3 = tw[(tid & 63) * (NC / 256)];                    // radix 4, NS = 64
-        b4 = tw[(tid & 255) * (NC / 1024)];                  // radix 4, NS = 256 (k = tid + b*T)
-        c4 = tw[T * (NC / 1024)];
-    } else {
-        b3 = tw[(tid & 63) * (NC / 512)];                    // radix 8, NS = 64
-        if constexpr (NC == 2048) { b4 = tw[(tid & 511) * (NC / 2048)]; c4 = tw[T * (NC / 2048)]; }
-        else if constexpr (NC == 4096) { b4 = tw[(tid & 511) * (NC / 4096)]; c4 = cmk(1.0, 0.0); }
-        else { b4 = cmk(1.0, 0.0); c4 = cmk(1.0, 0.0); }
-    }
+    if constexpr (NC == 1024) b3 = tw[(tid & 63) * (NC / 256)];      // radix 4, NS = 64
+    else b3 = tw[(tid & 63) * (NC / 512)];                           // radix 8, NS = 64
+    b4 = cmk(1.0, 0.0); c4 = cmk(1.0, 0.0);
+    if constexpr (NC == 1024 || NC == 2048) {                // last pass radix 4, NS = NC/4: k = j
+        b4 = tw[tid];
+        c4 = tw[tid == 0 ? NC / 8 : NC / 4 - tid];           // mirrored butterfly j2 (fused split)
+    } else if constexpr (NC == 4096) b4 = tw[tid & 511];
 }
 
-// Bins owned by a thread after the FFT: slot 2m -> bin k(m) = tid + m*NC/8,
-// slot 2m+1 -> bin NC - k(m).  Thread 0's first pair would be (DC, Nyquist),
-// which are not carriers; it owns the self-mirrored bin NC/2 there instead.
-// Only exp(-2 pi i tid / N) is kept; the other pair twiddles follow from it by
-// constant sixteenth-turn rotations (k advances by NC/8 = N/16 per m).
-template <int NC> struct PairMap {
-    cplx wb;              // exp(-2 pi i tid / (2 NC))
-    int tid;
-    GF3_DEV void init(int t, const cplx* __restrict__ twn) { tid = t; wb = twn[t]; }
-    GF3_DEV void reseat(int t) { tid = t; }
-    GF3_DEV int k(int m) const { return (m == 0 && tid == 0) ? NC / 2 : tid + m * (NC / 8); }
-    GF3_DEV cplx w(int m) const {
-        // exp(-2 pi i m / 16), m = 0..3
-        const cplx r16[4] = {cmk(1.0, 0.0), cmk(0.92387953251128675613, -0.38268343236508977173),
-                             cmk(GF3_SQRT1_2, -GF3_SQRT1_2), cmk(0.38268343236508977173, -0.92387953251128675613)};
-        if (m == 0) return tid == 0 ? cmk(0.0, -1.0) : wb;       // bin NC/2: exp(-i pi/2)
-        return cmul(wb, r16[m]);
+// Real FFT of one packed symbol with the spectrum left in registers in Spec<NC> slot order.
+// In: v[r] = z[t + r*NC/8] (t = threadIdx.x); wb = exp(-2 pi i t / (2NC)); z0 (thread 0) = Z[0].
+template <int NC>
+GF3_DEV void rfft_regs(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, cplx wb, int t, cplx& z0) {
+    if constexpr (Spec<NC>::FUSED) {
+        constexpr int Q = NC / 4;
+        fft_passes<NC, false>(v, lds, ft, t);
+        // last pass (radix 4, NS = Q) on butterflies j1 = t and j2 = Q - t, whose outputs mirror
+        // each other: Z[j1 + rQ] <-> Z[j2 + (3-r)Q].  Thread 0 takes the two self-mirrored ones.
+        const int j2 = (t == 0) ? Q / 2 : Q - t;
+        cplx a[4], b[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { a[r] = lds[t + r * Q]; b[r] = lds[j2 + r * Q]; }
+        twiddle_mul<4>(a, ft.b4);
+        twiddle_mul<4>(b, ft.c4);
+        bfly4(a);
+        bfly4(b);
+        z0 = a[0];
+        const bool t0 = (t == 0);
+        auto sel = [&](cplx x, cplx y) { return cmk(t0 ? x.x : y.x, t0 ? x.y : y.y); };
+        const cplx A[4] = {sel(a[2], a[0]), a[1], sel(b[0], a[2]), sel(b[1], a[3])};
+        const cplx Bm[4] = {sel(a[2], b[3]), sel(a[3], b[2]), sel(b[3], b[1]), sel(b[2], b[0])};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) real_split(A[r], Bm[r], Spec<NC>::pair_tw(t, r, wb), v[2 * r], v[2 * r + 1]);
+    } else {
+        fft_passes<NC, true>(v, lds, ft, t);
+        z0 = lds[0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = Spec<NC>::bin(t, 2 * r);
+            const cplx A = lds[k], Bm = lds[NC - k];
+            real_split(A, Bm, Spec<NC>::pair_tw(t, r, wb), v[2 * r], v[2 * r + 1]);
+        }
     }
-    // packed-real split: X[k], X[NC-k] of the 2NC-point real DFT from Z in LDS
-    GF3_DEV void split(const cplx* lds, int m, cplx& Xk, cplx& Xm) const {
-        const int kk = k(m);
-        const cplx A = lds[kk];
-        const cplx B = cconj(lds[NC - kk]);
-        const cplx E = cscale(cadd(A, B), 0.5);
-        const cplx O = cmul(mul_negi(cscale(csub(A, B), 0.5)), w(m));
-        Xk = cadd(E, O);
-        Xm = cconj(csub(E, O));
-    }
-};
+}
 
 // ---------------------------------------------------------------- block collectives
 GF3_DEV double wave_incl_scan(double x) {
@@ -352,9 +414,10 @@ GF3_DEV cplx cis_fast(double x) { double s, c; sincos_fast(x, s, c); return cmk(
 // np.unwrap's correction for one phase step dd = p[n] - p[n-1]
 GF3_DEV double unwrap_corr(double dd) {
     const double PI = 3.14159265358979323846, TWO_PI = 6.28318530717958647692;
-    double x = dd + PI;
-    double m = fmod(x, TWO_PI);                 // np.mod: result takes the divisor's sign
-    if (m != 0.0) { if (m < 0.0) m += TWO_PI; } else m = 0.0;
+    // np.mod(dd + pi, 2 pi): dd is a difference of two angles in [-pi, pi], so one conditional
+    // add/subtract reproduces fmod + sign fix-up exactly (the subtraction is exact by Sterbenz)
+    double m = dd + PI;
+    if (m >= TWO_PI) m -= TWO_PI; else if (m < 0.0) m += TWO_PI;
     double ddmod = m - PI;
     if (ddmod == -PI && dd > 0.0) ddmod = PI;
     double corr = ddmod - dd;
