@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     //      Hest = (a0 + da f_l) u exp(j slope n f_l),  u = Hs/|Hs| = exp(j angle(Hs))
     // Only the carriers inside the fit range need their angles: unwrap corrections before
     // fit_lo shift every fitted point by the same constant, which a slope does not see.
-    __syncthreads();                                  // FFT buffer is free: reuse it for the phases
+    lds_barrier();                                  // FFT buffer is free: reuse it for the phases
     double* ph0 = (double*)lds;
     double* ph1 = ph0 + NC;
     cplx u[8];
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         const double ia = rcp_nr(ahs);
         u[s] = cmk(hs.x * ia, hs.y * ia);
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase slope: unwrap(angle(He)) - unwrap(angle(Hs)), LS fit (OFDM.py:454-462)
     double slope;
@@ -285,6 +285,30 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     auto pack_words = [&](int l, bool tail) {
         const int wlo = (l * Bs) >> 5, whi = ((l + 1) * Bs) >> 5;
         const int nlab = D * C;                                            // labels in the packet
+        if (mu == 2 && (C & 1) == 0) {
+            // QPSK, even C: a word is 16 labels = 4 aligned dwords of the ring; one multiply moves
+            // the four 2-bit labels of a dword into a byte (label i -> bits 7-2i of it)
+            for (int w = wlo + launder(tid); w < whi + (tail ? 1 : 0); w += T) {
+                const int i0 = 16 * w;
+                int r = i0 % (2 * C);
+                uint32_t x = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t d4 = (i0 + 4 * j < nlab) ? *(const uint32_t*)(labs + r) : 0u;
+                    if (i0 + 4 * j + 4 > nlab) d4 &= 0xffffffffu >> (8 * (i0 + 4 * j + 4 - nlab));   // C even => whole pairs
+                    x = (x << 8) | ((d4 * 0x40100401u) >> 24);
+                    r += 4; if (r >= 2 * C) r -= 2 * C;
+                }
+                if (w < whi) {
+                    if ((a.row_bytes & 3) == 0) ((uint32_t*)row)[w] = __builtin_bswap32(x);
+                    else { row[4 * w] = x >> 24; row[4 * w + 1] = x >> 16; row[4 * w + 2] = x >> 8; row[4 * w + 3] = x; }
+                } else {
+                    const int rem = (D * Bs) & 31;
+                    for (int bb = 0; bb < ((rem + 7) >> 3); ++bb) row[4 * w + bb] = (uint8_t)(x >> (24 - 8 * bb));
+                }
+            }
+            return;
+        }
         for (int w = wlo + launder(tid); w < whi + (tail ? 1 : 0); w += T) {
             int i = (32 * w) / mu;                                         // first label touching the word
             const int skip = 32 * w - i * mu;
@@ -316,7 +340,8 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     auto build_rot = [&](int l) {
         const double phi_l = slope * (((double)l + 0.5 * (double)P) / denom);
         cplx* tb = rtab + (l & 1) * (64 + NTH);
-        for (int i = launder(tid); i < 64 + NTH; i += T)
+        // built by the upper half of the block: the lower half packs the previous symbol's bits
+        for (int i = (launder(tid) + T / 2) % T; i < 64 + NTH; i += T)
             tb[i] = cis_fast(phi_l * (double)(i < 64 ? i - 1 : 64 * (i - 64)));
     };
     auto rot_of = [&](const cplx* tb, int n) {
@@ -325,7 +350,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     };
     for (int l = 0; l < D; ++l) {
         build_rot(l);
-        if constexpr (SPECTRA) { __syncthreads(); load_spectra(a.sp_data + ((int64_t)f * D + l) * K); }
+        if constexpr (SPECTRA) { lds_barrier(); load_spectra(a.sp_data + ((int64_t)f * D + l) * K); }
         else transform(2 * P + l);
         if (l > 0) pack_words(l - 1, false);
         const double fl = ((double)l + 0.5 * (double)P) / denom;          // (l + P/2)/(D+P)
@@ -368,7 +393,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     pack_words(D - 1, ((D * Bs) & 31) != 0);
 }
 
@@ -443,7 +468,7 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) 
         }
     }
     // ---- inverse real FFT of the accumulated Hermitian spectrum Y
-    __syncthreads();
+    lds_barrier();
     {
         const int tq = launder(tid);
 #pragma unroll
@@ -463,14 +488,14 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) 
         const double E = 0.5 * (accDC + accNy), Op = 0.5 * (accDC - accNy);
         lds[0] = cmk(E, -Op);                                               // conj(E + i Op)
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = lds[tid + r * T];
     fft_core<NC>(v, lds, ft, launder(tid));
     // z = conj(FFT(conj Z))/NC ; y[2n] = Re z, y[2n+1] = Im z  -> in place as doubles
     const double inv = 1.0 / (double)NC;
     for (int i = tid; i < NC; i += T) { const cplx z = lds[i]; lds[i] = cmk(z.x * inv, -z.y * inv); }
-    __syncthreads();
+    lds_barrier();
     const double* y = (const double*)lds;
 
     if (!frames) {

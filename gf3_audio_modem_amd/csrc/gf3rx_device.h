@@ -41,6 +41,11 @@ GF3_DEV cplx cdiv_np(cplx a, cplx b) {
     return cmk((a.x * rat + a.y) * scl, (a.y * rat - a.x) * scl);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0),
+// which would make every FFT barrier wait for the next symbol's prefetch loads; here global
+// loads stay in flight across the barrier (their consumers get their own s_waitcnt).
+GF3_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Opaque copy of a per-thread index.  Everything derived from the copy is recomputed where it
 // is used instead of being hoisted out of the symbol loop and kept live (or spilled) across it.
 GF3_DEV int launder(int x) { asm volatile("" : "+v"(x)); return x; }
@@ -150,7 +155,7 @@ GF3_DEV void fft_pass(cplx (&v)[8], cplx* lds, cplx wbase, cplx wstep, int tid) 
 #pragma unroll
         for (int r = 0; r < R; ++r) v[b * R + r] = lds[j + r * (NC / R)];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = tid + b * T;
@@ -163,7 +168,7 @@ GF3_DEV void fft_pass(cplx (&v)[8], cplx* lds, cplx wbase, cplx wstep, int tid) 
 #pragma unroll
         for (int r = 0; r < R; ++r) lds[base + r * NS] = v[b * R + r];
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // Slot layout of one real-FFT result held in registers: thread t owns 8 bins,
@@ -224,13 +229,13 @@ template <int NC, bool ALL>
 GF3_DEV void fft_passes(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid) {
     constexpr int T = NC / 8;
     bfly8(v);
-    __syncthreads();                       // previous users of the buffer are done
+    lds_barrier();                       // previous users of the buffer are done
 #pragma unroll
     for (int r = 0; r < 8; ++r) lds[tid * 9 + r] = v[r];          // logical tid*8+r, padded
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < 8; ++r) { const int i = tid + r * T; v[r] = lds[i + (i >> 3)]; }
-    __syncthreads();
+    lds_barrier();
     {
         const int k = tid & 7;
         twiddle_mul<8>(v, ft.b2);
@@ -239,7 +244,7 @@ GF3_DEV void fft_passes(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) lds[base + r * 8] = v[r];
     }
-    __syncthreads();
+    lds_barrier();
     const cplx w8 = cmk(GF3_SQRT1_2, -GF3_SQRT1_2);              // exp(-i pi/4): T steps of the last pass
     if constexpr (NC == 512) {
         fft_pass<NC, 8, 64>(v, lds, ft.b3, w8, tid);
@@ -338,9 +343,9 @@ GF3_DEV int wave_min_i(int x) {
 GF3_DEV double block_sum(double x, double* scratch) {
     const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     x = wave_sum(x);
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) scratch[wave] = x;
-    __syncthreads();
+    lds_barrier();
     double s = 0.0;
     for (int i = 0; i < nw; ++i) s += scratch[i];
     return s;
@@ -348,9 +353,9 @@ GF3_DEV double block_sum(double x, double* scratch) {
 GF3_DEV double block_max(double x, double* scratch) {
     const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     x = wave_max(x);
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) scratch[wave] = x;
-    __syncthreads();
+    lds_barrier();
     double s = scratch[0];
     for (int i = 1; i < nw; ++i) s = fmax(s, scratch[i]);
     return s;
@@ -358,9 +363,9 @@ GF3_DEV double block_max(double x, double* scratch) {
 GF3_DEV int block_min_i(int x, int* scratch) {
     const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     x = wave_min_i(x);
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) scratch[wave] = x;
-    __syncthreads();
+    lds_barrier();
     int s = scratch[0];
     for (int i = 1; i < nw; ++i) s = min(s, scratch[i]);
     return s;
@@ -369,9 +374,9 @@ GF3_DEV int block_min_i(int x, int* scratch) {
 GF3_DEV void block_excl_scan2(double a, double b, double* scratch, double& ea, double& eb) {
     const int wave = threadIdx.x >> 6;
     const double ia = wave_incl_scan(a), ib = wave_incl_scan(b);
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 63) { scratch[wave] = ia; scratch[8 + wave] = ib; }
-    __syncthreads();
+    lds_barrier();
     double oa = 0.0, ob = 0.0;
     for (int i = 0; i < wave; ++i) { oa += scratch[i]; ob += scratch[8 + i]; }
     ea = oa + (ia - a);
