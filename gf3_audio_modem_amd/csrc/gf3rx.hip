@@ -43,7 +43,15 @@ struct DemodArgs {
     const cplx* sp_end;       // [F, P, K]
     cplx* eq_all;             // [F*D, K] equalised symbols on all carriers
     double qpsk_q;            // >0: table is the reference QPSK table (+-q +-qj): decide by signs away from ties
+    unsigned long long* stamps;   // diagnostic build only (-DGF3_STAMPS): [F][8] s_memtime per phase
 };
+
+#ifdef GF3_STAMPS
+#define GF3_STAMP(i) do { if (a.stamps && threadIdx.x == 0) { unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); a.stamps[blockIdx.x * 8 + (i)] = t_; } } while (0)
+#else
+#define GF3_STAMP(i) do { } while (0)
+#endif
 
 // occupancy targets: min waves per SIMD handed to __launch_bounds__ (blocks of NC/8 threads).
 // 2048 -> 3 blocks of 4 waves per CU (<=168 VGPRs), 4096 -> 1 block of 8 waves (<=256).
@@ -194,13 +202,18 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2) v[s2] = sp[bin_of(s2) - 1];
     };
+    GF3_STAMP(0);
     if constexpr (!SPECTRA) fetch(0);
+    cplx ik[8];                                       // 1/known for this thread's carriers
+#pragma unroll
+    for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
 
     // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451)
     cplx Hs[8], He[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) Hs[s] = He[s] = cmk(0.0, 0.0);
     for (int i = 0; i < 2 * P; ++i) {
+        if (i == 1) GF3_STAMP(1);
         const bool side = i >= P;
         if constexpr (SPECTRA) load_spectra((side ? a.sp_end : a.sp_start) + ((int64_t)f * P + (side ? i - P : i)) * K);
         else transform(i);
@@ -212,27 +225,33 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 
     // ---- per carrier: H = mean / known; equaliser state
     //      Hest = (a0 + da f_l) u exp(j slope n f_l),  u = Hs/|Hs| = exp(j angle(Hs))
-    // Only the carriers inside the fit range need their angles: unwrap corrections before
-    // fit_lo shift every fitted point by the same constant, which a slope does not see.
-    lds_barrier();                                  // FFT buffer is free: reuse it for the phases
+    // Phase slope (OFDM.py:454-462): y_n = unwrap(angle He)_n - unwrap(angle Hs)_n fitted over
+    // n in [fit_lo, fit_hi).  With c_n = sum_{i<=n} e_i the cumulative unwrap corrections,
+    //   sum_n xm_n c_n = sum_i e_i S_i,  S_i = sum_{n>=i} xm_n = j (L - j) / 2,  j = i - fit_lo,
+    // so the fit needs no prefix scan, and corrections before fit_lo (a common offset of every
+    // fitted point) drop out: only carriers inside the fit range need their angles.
+    GF3_STAMP(2);
+    lds_barrier();                                    // FFT buffer is free: reuse it for the phases
     double* ph0 = (double*)lds;
     double* ph1 = ph0 + NC;
     cplx u[8];
-    double a0[8], da[8];
+    double a0[8], da[8], p0[8], p1[8];
     const double invP = 1.0 / (double)P;
     tq = launder(tid);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int bn = bin_of(s);
-        const cplx ik = a.inv_known[bn - 1];
-        const cplx hs = cmul(cscale(Hs[s], invP), ik);
-        const cplx he = cmul(cscale(He[s], invP), ik);
+        const cplx hs = cmul(cscale(Hs[s], invP), ik[s]);
+        const cplx he = cmul(cscale(He[s], invP), ik[s]);
+        p0[s] = 0.0; p1[s] = 0.0;
         if (live_of(s)) {
             if (a.Hs) a.Hs[f * K + bn - 1] = hs;
             if (a.He) a.He[f * K + bn - 1] = he;
             if (bn - 1 >= a.fit_lo && bn - 1 < a.fit_hi) {
-                ph0[bn - 1] = atan2(hs.y, hs.x);
-                ph1[bn - 1] = atan2(he.y, he.x);
+                p0[s] = atan2_fast(hs.y, hs.x);
+                p1[s] = atan2_fast(he.y, he.x);
+                ph0[bn - 1] = p0[s];
+                ph1[bn - 1] = p1[s];
             }
         }
         const double ahs = sqrt(hs.x * hs.x + hs.y * hs.y);
@@ -244,38 +263,27 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         u[s] = cmk(hs.x * ia, hs.y * ia);
     }
     lds_barrier();
-
-    // ---- phase slope: unwrap(angle(He)) - unwrap(angle(Hs)), LS fit (OFDM.py:454-462)
     double slope;
     {
-        const int n0 = tid * 8;
-        double c0[8], c1[8], r0 = 0.0, r1 = 0.0;
-        const bool touch = n0 + 8 > a.fit_lo && n0 < a.fit_hi;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = n0 + i;
-            if (touch && n > a.fit_lo && n < a.fit_hi) {
-                r0 += unwrap_corr(ph0[n] - ph0[n - 1]);
-                r1 += unwrap_corr(ph1[n] - ph1[n - 1]);
-            }
-            c0[i] = r0; c1[i] = r1;
-        }
-        double e0, e1;
-        block_excl_scan2(r0, r1, scratch, e0, e1);
         double acc = 0.0;
-        if (touch) {
+        const int L = a.fit_hi - a.fit_lo;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int n = n0 + i;
-                if (n >= a.fit_lo && n < a.fit_hi) {
-                    const double y = (ph1[n] + (e1 + c1[i])) - (ph0[n] + (e0 + c0[i]));
-                    acc += y * ((double)(n - a.fit_lo) - a.xbar);
+        for (int s = 0; s < 8; ++s) {
+            const int n = bin_of(s) - 1;
+            if (live_of(s) && n >= a.fit_lo && n < a.fit_hi) {
+                const int j = n - a.fit_lo;
+                acc += ((double)j - a.xbar) * (p1[s] - p0[s]);
+                if (j > 0) {
+                    const double e0 = unwrap_corr(p0[s] - ph0[n - 1]);
+                    const double e1 = unwrap_corr(p1[s] - ph1[n - 1]);
+                    acc += (e1 - e0) * (0.5 * (double)j * (double)(L - j));
                 }
             }
         }
         slope = block_sum(acc, scratch + 16) * a.inv_sxx;
     }
     if (tid == 0 && a.slope) a.slope[f] = slope;
+    GF3_STAMP(3);
 
     // ---- data symbols: FFT -> /Hest -> demap -> bit-pack (OFDM.py:466-478, 487-505)
     // Decisions are staged as one byte per data carrier in a two-symbol LDS ring and
@@ -393,8 +401,10 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
             }
         }
     }
+    GF3_STAMP(4);
     lds_barrier();
     pack_words(D - 1, ((D * Bs) & 31) != 0);
+    GF3_STAMP(5);
 }
 
 // ============================================================================
@@ -674,6 +684,7 @@ struct gf3_ctx {
     double *d_cre = nullptr, *d_cim = nullptr;
     CorrPlan frames_plan, stream_plan;
     double qpsk_q = 0.0;
+    unsigned long long* stamps = nullptr;
     int contig_lo = 0;
     std::vector<double> chirp;
     mutable char err[512];
@@ -873,6 +884,9 @@ extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
     delete c;
 }
 
+// diagnostic builds only: device buffer [F][8] of uint64 that receives per-phase s_memtime stamps
+extern "C" void gf3_debug_set_stamps(gf3_ctx* c, void* d_buf) { if (c) c->stamps = (unsigned long long*)d_buf; }
+
 extern "C" int32_t gf3_bytes_per_frame(const gf3_ctx* c) { return c ? c->row_bytes : 0; }
 extern "C" int32_t gf3_sync_max_window(const gf3_ctx* c) { return c ? c->frames_plan.W : 0; }
 
@@ -906,7 +920,7 @@ extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, cons
                 c->d_known, c->d_pos, c->contig_lo, c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, (cplx*)d_eq, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, d_status,
-                nullptr, nullptr, nullptr, nullptr, c->qpsk_q};
+                nullptr, nullptr, nullptr, nullptr, c->qpsk_q, c->stamps};
     hipError_t e = hipSuccess;
     if (d_eq || d_Hest) {
         DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_FULL>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
@@ -930,7 +944,7 @@ extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start,
                 c->d_known, c->d_pos, c->contig_lo, c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, nullptr, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, nullptr,
-                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_q};
+                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_q, nullptr};
     hipError_t e = hipSuccess;
     switch (c->NC) {
 #ifndef GF3_DEV_BUILD

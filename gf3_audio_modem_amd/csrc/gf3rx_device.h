@@ -416,6 +416,32 @@ GF3_DEV double rcp_nr(double x) {
 }
 GF3_DEV cplx cis_fast(double x) { double s, c; sincos_fast(x, s, c); return cmk(c, s); }
 
+// atan2 with fdlibm's atan kernel (break points 7/16, 11/16; 11-term odd polynomial),
+// branch-free apart from selects: a = min/max in [0,1], reduce, evaluate, unfold octants.
+// <= ~2 ulp; only feeds the phase-slope fit (tolerance 1e-11).
+GF3_DEV double atan2_fast(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const double a = mn * rcp_nr(mx);
+    const bool lo = a < 0.4375, mid = a < 0.6875;
+    const double num = lo ? a : (mid ? 2.0 * a - 1.0 : a - 1.0);
+    const double den = lo ? 1.0 : (mid ? 2.0 + a : a + 1.0);
+    const double t = num * rcp_nr(den);
+    const double hi = lo ? 0.0 : (mid ? 4.63647609000806093515e-01 : 7.85398163397448278999e-01);
+    const double lw = lo ? 0.0 : (mid ? 2.26987774529616870924e-17 : 3.06161699786838301793e-17);
+    const double z = t * t, w = z * z;
+    const double s1 = z * fma(w, fma(w, fma(w, fma(w, fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02),
+                      6.66107313738753120669e-02), 9.09088713343650656196e-02), 1.42857142725034663711e-01),
+                      3.33333333333329318027e-01);
+    const double s2 = w * fma(w, fma(w, fma(w, fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02),
+                      -7.69187620504482999495e-02), -1.11111104054623557880e-01), -1.99999999998764832476e-01);
+    double r = hi - ((t * (s1 + s2) - lw) - t);
+    if (!(mx > 0.0)) r = 0.0;                       // atan2(0, 0) = 0 (NaN stays NaN through mx)
+    if (ay > ax) r = 1.57079632679489655800 - r;
+    if (x < 0.0) r = 3.14159265358979311600 - r;
+    return y < 0.0 ? -r : r;
+}
+
 // np.unwrap's correction for one phase step dd = p[n] - p[n-1]
 GF3_DEV double unwrap_corr(double dd) {
     const double PI = 3.14159265358979323846, TWO_PI = 6.28318530717958647692;

@@ -83,6 +83,10 @@ int gf3_ctx_create(const gf3_config *cfg, gf3_ctx **out);
 void gf3_ctx_destroy(gf3_ctx *ctx);
 const char *gf3_last_error(const gf3_ctx *ctx);
 
+/* diagnostics: in a library built with -DGF3_STAMPS, gf3_demod_frames writes eight s_memtime
+ * stamps per frame into this device buffer ([F][8] uint64); a no-op in the product build */
+void gf3_debug_set_stamps(gf3_ctx *ctx, void *d_buf_u64);
+
 /* derived sizes a caller needs to allocate outputs */
 int32_t gf3_bytes_per_frame(const gf3_ctx *ctx);     /* ceil(D*C*mu/8)            */
 int32_t gf3_sync_max_window(const gf3_ctx *ctx);     /* lags one gf3_sync_frames block resolves */

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase s_memtime shares of the fused demod kernel (needs a library built with
+-DGF3_STAMPS: GF3_LIB=/path/to/lib python tools/stamps.py).  Never quote this build's run time."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, ctypes as C
+from gf3_audio_modem_amd import build
+if os.environ.get("GF3_LIB"): build.LIB = os.environ["GF3_LIB"]
+from gf3_audio_modem_amd import Engine, RxConfig, qpsk_table, synth
+
+N, CP, P, D, F = 4096, 512, 2, 8, 16384
+K = N // 2 - 1
+pts, bt = qpsk_table()
+known = np.unpackbits(np.load(os.path.join(os.path.dirname(__file__), "..", "gf3_audio_modem_amd", "data", "known_bits.npz"))["packed"])
+cfg = RxConfig(N=N, CP=CP, P=P, D=D, data_bins=np.arange(1, K), const_points=pts, const_bits=bt, known_bits=known,
+               in_dtype=torch.float32, max_window=320)
+eng = Engine(cfg)
+stride = 78720
+rows, payload, gaps = synth.make_frames(cfg, eng.chirp_replica(), 32, seed=1, stride=stride, dtype=torch.float32)
+big = synth.tile_rows(rows, F)
+starts = eng.sync_frames(big, F, stride, 0, 320)
+st = torch.zeros((F, 8), dtype=torch.int64, device="cuda")
+eng.lib.gf3_debug_set_stamps(eng._h, C.c_void_p(st.data_ptr()))
+for _ in range(3):
+    eng.demod_frames(big, starts)
+torch.cuda.synchronize()
+s = st.cpu().numpy().astype(np.float64)
+d = np.diff(s[:, :6], axis=1)
+names = ["start -> first pilot done", "remaining pilots", "finalize (H, angles, slope)", "data symbols", "last pack + exit"]
+tot = s[:, 5] - s[:, 0]
+print("median block lifetime (s_memtime ticks):", np.median(tot))
+for i, nme in enumerate(names):
+    print(f"  {nme:32s} median {np.median(d[:, i]):10.0f}  share {np.median(d[:, i]) / np.median(tot):6.1%}")
