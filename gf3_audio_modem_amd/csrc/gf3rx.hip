@@ -92,7 +92,7 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void rfft_kernel(RfftArgs a) 
         v[r] = raw.get();
     }
     cplx z0;
-    rfft_regs<NC>(v, smem, ft, wb, tid, z0);
+    rfft_regs<NC>(v, smem, ft, wb, tid, z0, 0);
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2)
         if (Spec<NC>::live(tid, s2)) out[Spec<NC>::bin(tid, s2)] = v[s2];
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (i + 1 < Msym) fetch(i + 1);
         tq = launder(tid);
-        rfft_regs<NC>(v, lds, ft, wb, tq, z0);
+        rfft_regs<NC>(v, lds, ft, wb, tq, z0, i & 1);
     };
     auto load_spectra = [&](const cplx* sp) {         // SPECTRA mode: slots straight from memory
         tq = launder(tid);
@@ -414,12 +414,19 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 //   c split into Q partitions of Lp taps; each partition's contribution is a
 //   circular correlation of size N = 2NC, valid for lags < N-Lp+1.
 // ============================================================================
+#ifndef GF3_CORR_WPS
+#define GF3_CORR_WPS 2
+#endif
+#ifndef GF3_CORR_PP
+#define GF3_CORR_PP true
+#endif
 template <int NC, int DT>
-__global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) {
+__global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_kernel(CorrArgs a) {
     extern __shared__ double2 smem[];
     constexpr int T = NC / 8;
+    constexpr bool PP = GF3_CORR_PP && FftGeom<NC>::PINGPONG;
     cplx* lds = smem;
-    double* scratch = (double*)(smem + FftGeom<NC>::LDS_ELEMS);
+    double* scratch = (double*)(smem + (PP ? FftGeom<NC>::LDS_ELEMS : FftGeom<NC>::LDS_ELEMS_INPLACE));
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
     const bool frames = a.starts != nullptr;
@@ -466,12 +473,9 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) 
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (q + 1 < a.Q) fetch(q + 1);
         const int tq = launder(tid);
-        cplx hq[8];
+        rfft_regs<NC, PP>(v, lds, ft, wb, tq, z0, q & 1);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec<NC>::bin(tq, s)];
-        rfft_regs<NC>(v, lds, ft, wb, tq, z0);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc[s] = cadd(acc[s], cmul_conj(v[s], hq[s]));
+        for (int s = 0; s < 8; ++s) acc[s] = cadd(acc[s], cmul_conj(v[s], Hq[Spec<NC>::bin(tq, s)]));
         if (tid == 0) {
             accDC += (z0.x + z0.y) * Hq[0].x;
             accNy += (z0.x - z0.y) * Hq[NC].x;
@@ -501,12 +505,13 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void corr_kernel(CorrArgs a) 
     lds_barrier();
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = lds[tid + r * T];
-    fft_core<NC>(v, lds, ft, launder(tid));
+    lds_barrier();                                   // everyone holds its inputs: both buffers are free
+    cplx* yb = fft_core<NC, PP>(v, lds, ft, launder(tid));
     // z = conj(FFT(conj Z))/NC ; y[2n] = Re z, y[2n+1] = Im z  -> in place as doubles
     const double inv = 1.0 / (double)NC;
-    for (int i = tid; i < NC; i += T) { const cplx z = lds[i]; lds[i] = cmk(z.x * inv, -z.y * inv); }
+    for (int i = tid; i < NC; i += T) { const cplx z = yb[i]; yb[i] = cmk(z.x * inv, -z.y * inv); }
     lds_barrier();
-    const double* y = (const double*)lds;
+    const double* y = (const double*)yb;
 
     if (!frames) {
         const int64_t m0 = b * (int64_t)a.V;
@@ -710,7 +715,9 @@ template <typename T> static hipError_t upload(T** dptr, const T* h, size_t n) {
     return hipMemcpy(*dptr, h, n * sizeof(T), hipMemcpyHostToDevice);
 }
 
-static size_t fft_lds_bytes(int NC) { return (size_t)(NC + NC / 8) * sizeof(cplx); }
+static size_t fft_lds_bytes(int NC) {          // == FftGeom<NC>::LDS_ELEMS
+    return (size_t)((NC == 1024 || NC == 2048) ? 2 * NC : NC + NC / 8) * sizeof(cplx);
+}
 
 template <typename Kern, typename Args>
 static hipError_t launch(Kern k, int64_t grid, int threads, size_t lds, hipStream_t st, const Args& a) {
@@ -959,7 +966,7 @@ extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start,
 }
 
 static hipError_t run_corr(const gf3_ctx* c, const CorrArgs& a, int64_t grid, hipStream_t st) {
-    const size_t lds = fft_lds_bytes(c->NC) + 32 * sizeof(double);
+    const size_t lds = (GF3_CORR_PP ? fft_lds_bytes(c->NC) : (size_t)(c->NC + c->NC / 8) * sizeof(cplx)) + 32 * sizeof(double);
     hipError_t e = hipSuccess;
     DISPATCH_NC(c->NC, a.dt, e = launch((corr_kernel<NCC, DTC>), grid, NCC / 8, lds, st, a));
     return e;

@@ -133,9 +133,15 @@ template <int R> GF3_DEV void twiddle_mul(cplx* v, cplx w) {
 // ---------------------------------------------------------------- LDS FFT
 // LDS footprint of one FFT buffer, in cplx elements (first exchange is padded
 // by one element per 8 to break the stride-8 store conflict).
+// Fused sizes (1024/2048): two NC-point buffers used ping-pong, so one barrier per exchange
+// (a pass never stores into the buffer other waves may still be loading from); the first,
+// stride-8, exchange is XOR-swizzled instead of padded.  Other sizes: one padded buffer, two
+// barriers per exchange.
 template <int NC> struct FftGeom {
     static constexpr int T = NC / 8;
-    static constexpr int LDS_ELEMS = NC + NC / 8;
+    static constexpr bool PINGPONG = (NC == 1024 || NC == 2048);
+    static constexpr int LDS_ELEMS = PINGPONG ? 2 * NC : NC + NC / 8;
+    static constexpr int LDS_ELEMS_INPLACE = NC + NC / 8;
 };
 
 // Per-thread twiddle bases: the index k of every pass depends only on the thread,
@@ -147,15 +153,15 @@ template <int NC> struct FftTw {
 };
 
 template <int NC, int R, int NS>
-GF3_DEV void fft_pass(cplx (&v)[8], cplx* lds, cplx wbase, cplx wstep, int tid) {
+GF3_DEV void fft_pass(cplx (&v)[8], const cplx* src, cplx* dst, cplx wbase, cplx wstep, int tid) {
     constexpr int T = NC / 8, NB = 8 / R;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = tid + b * T;
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[b * R + r] = lds[j + r * (NC / R)];
+        for (int r = 0; r < R; ++r) v[b * R + r] = src[j + r * (NC / R)];
     }
-    lds_barrier();
+    if (src == dst) lds_barrier();                          // in place: all loads before any store
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = tid + b * T;
@@ -166,7 +172,7 @@ GF3_DEV void fft_pass(cplx (&v)[8], cplx* lds, cplx wbase, cplx wstep, int tid) 
         bfly<R>(&v[b * R]);
         const int base = (j - k) * R + k;
 #pragma unroll
-        for (int r = 0; r < R; ++r) lds[base + r * NS] = v[b * R + r];
+        for (int r = 0; r < R; ++r) dst[base + r * NS] = v[b * R + r];
     }
     lds_barrier();
 }
@@ -223,48 +229,67 @@ GF3_DEV void real_split(cplx A, cplx Bm, cplx w, cplx& Xk, cplx& Xm) {
     Xm = cconj(csub(E, O));
 }
 
-// passes 1..2 (radix 8) and, where there are four passes, pass 3; leaves the Stockham
-// intermediate in LDS.  In: v[r] = z[tid + r*NC/8].
-template <int NC, bool ALL>
-GF3_DEV void fft_passes(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid) {
+// Passes through LDS.  In: v[r] = z[tid + r*NC/8].  ALL = false stops before the last pass
+// (fused sizes).  `flip` selects which ping-pong buffer the first exchange uses; the caller
+// alternates it per transform.  Returns the buffer that holds the result.
+template <int NC, bool ALL, bool PP = FftGeom<NC>::PINGPONG>
+GF3_DEV cplx* fft_passes(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid, int flip) {
     constexpr int T = NC / 8;
+    const cplx w8 = cmk(GF3_SQRT1_2, -GF3_SQRT1_2);              // exp(-i pi/4): T steps of the last pass
+    cplx* A = PP ? lds + (flip ? NC : 0) : lds;
+    cplx* B = PP ? lds + (flip ? 0 : NC) : lds;
     bfly8(v);
-    lds_barrier();                       // previous users of the buffer are done
+    if constexpr (PP) {
+        // exchange 1, XOR-swizzled: logical i = tid*8 + r  ->  i ^ ((i >> 3) & 7)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) lds[tid * 9 + r] = v[r];          // logical tid*8+r, padded
-    lds_barrier();
+        for (int r = 0; r < 8; ++r) A[tid * 8 + (r ^ (tid & 7))] = v[r];
+        lds_barrier();
+        const int ts = tid ^ ((tid >> 3) & 7);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { const int i = tid + r * T; v[r] = lds[i + (i >> 3)]; }
-    lds_barrier();
+        for (int r = 0; r < 8; ++r) v[r] = A[ts + r * T];
+    } else {
+        lds_barrier();                     // previous users of the buffer are done
+#pragma unroll
+        for (int r = 0; r < 8; ++r) A[tid * 9 + r] = v[r];        // logical tid*8+r, padded
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const int i = tid + r * T; v[r] = A[i + (i >> 3)]; }
+        lds_barrier();
+    }
     {
         const int k = tid & 7;
         twiddle_mul<8>(v, ft.b2);
         bfly8(v);
         const int base = (tid - k) * 8 + k;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) lds[base + r * 8] = v[r];
+        for (int r = 0; r < 8; ++r) B[base + r * 8] = v[r];
     }
     lds_barrier();
-    const cplx w8 = cmk(GF3_SQRT1_2, -GF3_SQRT1_2);              // exp(-i pi/4): T steps of the last pass
     if constexpr (NC == 512) {
-        fft_pass<NC, 8, 64>(v, lds, ft.b3, w8, tid);
+        fft_pass<NC, 8, 64>(v, B, A, ft.b3, w8, tid);
+        return A;
     } else if constexpr (NC == 1024) {
-        fft_pass<NC, 4, 64>(v, lds, ft.b3, w8, tid);
-        if constexpr (ALL) fft_pass<NC, 4, 256>(v, lds, ft.b4, w8, tid);
+        fft_pass<NC, 4, 64>(v, B, A, ft.b3, w8, tid);
+        if constexpr (ALL) { fft_pass<NC, 4, 256>(v, A, B, ft.b4, w8, tid); return B; }
+        return A;
     } else if constexpr (NC == 2048) {
-        fft_pass<NC, 8, 64>(v, lds, ft.b3, w8, tid);
-        if constexpr (ALL) fft_pass<NC, 4, 512>(v, lds, ft.b4, w8, tid);
+        fft_pass<NC, 8, 64>(v, B, A, ft.b3, w8, tid);
+        if constexpr (ALL) { fft_pass<NC, 4, 512>(v, A, B, ft.b4, w8, tid); return B; }
+        return A;
     } else {
         static_assert(NC == 4096, "unsupported FFT size");
-        fft_pass<NC, 8, 64>(v, lds, ft.b3, w8, tid);
-        fft_pass<NC, 8, 512>(v, lds, ft.b4, w8, tid);
+        fft_pass<NC, 8, 64>(v, B, A, ft.b3, w8, tid);
+        fft_pass<NC, 8, 512>(v, A, B, ft.b4, w8, tid);
+        return B;
     }
 }
 
-// Forward complex FFT of NC points, result Z[0..NC) in natural order in lds[0..NC).
-template <int NC>
-GF3_DEV void fft_core(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid) {
-    fft_passes<NC, true>(v, lds, ft, tid);
+// Forward complex FFT of NC points; returns the LDS buffer holding Z[0..NC) in natural order.
+// Ping-pong sizes: the caller must have a barrier between the last reads of both buffers by a
+// previous user and this call (this entry point is only used after such a barrier).
+template <int NC, bool PP = FftGeom<NC>::PINGPONG>
+GF3_DEV cplx* fft_core(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid) {
+    return fft_passes<NC, true, PP>(v, lds, ft, tid, 0);
 }
 
 template <int NC> GF3_DEV void FftTw<NC>::init(int tid, const cplx* __restrict__ tw) {
@@ -280,17 +305,20 @@ template <int NC> GF3_DEV void FftTw<NC>::init(int tid, const cplx* __restrict__
 
 // Real FFT of one packed symbol with the spectrum left in registers in Spec<NC> slot order.
 // In: v[r] = z[t + r*NC/8] (t = threadIdx.x); wb = exp(-2 pi i t / (2NC)); z0 (thread 0) = Z[0].
-template <int NC>
-GF3_DEV void rfft_regs(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, cplx wb, int t, cplx& z0) {
+// `flip` must alternate between consecutive calls in a workgroup (ping-pong hazard: the last
+// pass of call i reads buffer A_i with no barrier after it; call i+1 starts by storing into the
+// other buffer, which every wave finished reading before call i's final barrier).
+template <int NC, bool PP = FftGeom<NC>::PINGPONG>
+GF3_DEV void rfft_regs(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, cplx wb, int t, cplx& z0, int flip) {
     if constexpr (Spec<NC>::FUSED) {
         constexpr int Q = NC / 4;
-        fft_passes<NC, false>(v, lds, ft, t);
+        const cplx* Z = fft_passes<NC, false, PP>(v, lds, ft, t, flip);
         // last pass (radix 4, NS = Q) on butterflies j1 = t and j2 = Q - t, whose outputs mirror
         // each other: Z[j1 + rQ] <-> Z[j2 + (3-r)Q].  Thread 0 takes the two self-mirrored ones.
         const int j2 = (t == 0) ? Q / 2 : Q - t;
         cplx a[4], b[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { a[r] = lds[t + r * Q]; b[r] = lds[j2 + r * Q]; }
+        for (int r = 0; r < 4; ++r) { a[r] = Z[t + r * Q]; b[r] = Z[j2 + r * Q]; }
         twiddle_mul<4>(a, ft.b4);
         twiddle_mul<4>(b, ft.c4);
         bfly4(a);
@@ -303,12 +331,12 @@ GF3_DEV void rfft_regs(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, cplx wb, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) real_split(A[r], Bm[r], Spec<NC>::pair_tw(t, r, wb), v[2 * r], v[2 * r + 1]);
     } else {
-        fft_passes<NC, true>(v, lds, ft, t);
-        z0 = lds[0];
+        const cplx* Z = fft_passes<NC, true, PP>(v, lds, ft, t, 0);
+        z0 = Z[0];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = Spec<NC>::bin(t, 2 * r);
-            const cplx A = lds[k], Bm = lds[NC - k];
+            const cplx A = Z[k], Bm = Z[NC - k];
             real_split(A, Bm, Spec<NC>::pair_tw(t, r, wb), v[2 * r], v[2 * r + 1]);
         }
     }
