@@ -1,0 +1,93 @@
+"""N>1 path on CPU: frame sharding + the single all-gather of packed bits, world size 2, gloo."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["GF3_ROOT"])
+import numpy as np, torch
+from gf3_audio_modem_amd import dist as gd
+rank, world, local = gd.init_from_env(backend="gloo")
+assert world == 2
+row = 37
+def rows_of(lo, hi):                      # packed bytes of frame f are a function of f only
+    f = np.arange(lo, hi)[:, None]; c = np.arange(row)[None, :]
+    return torch.from_numpy(((f * 131 + c * 7 + 3) % 251).astype(np.uint8))
+for F_total in (8, 5, 2, 3):
+    lo, hi = gd.shard_range(F_total, rank, world)
+    mine = rows_of(lo, hi)
+    full = gd.all_gather_bits(mine, F_total)
+    assert full.shape == (F_total, row), full.shape
+    assert torch.equal(full, rows_of(0, F_total)), F_total
+    if F_total % world == 0:              # preallocated output, the path bench.py uses
+        out = torch.empty((F_total, row), dtype=torch.uint8)
+        gd.all_gather_bits(mine, out=out)
+        assert torch.equal(out, rows_of(0, F_total))
+t = gd.max_over_ranks(float(rank + 1), torch.device("cpu"))
+assert t == 2.0
+gd.barrier()
+import torch.distributed as dist
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_shard_range_partitions_every_frame_once():
+    from gf3_audio_modem_amd.dist import shard_range
+    for F in (0, 1, 7, 8, 65536, 1048576 + 3):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(F, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == F
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_all_gather_bits_two_ranks_gloo(tmp_path):
+    port = _free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GF3_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+
+
+def test_single_process_is_identity():
+    import torch
+    from gf3_audio_modem_amd import dist as gd
+    x = torch.arange(12, dtype=torch.uint8).reshape(3, 4)
+    assert gd.all_gather_bits(x) is x
+    assert gd.max_over_ranks(1.5, torch.device("cpu")) == 1.5
+
+
+def test_unpack_bits_layout_cpu():
+    """Engine.unpack_bits is pure layout (torch ops): check it against np.unpackbits without a GPU."""
+    import torch
+    from gf3_audio_modem_amd.engine import Engine, RxConfig
+
+    class Fake:
+        cfg = RxConfig(N=1024, CP=0, P=1, D=3, data_bins=np.arange(1, 6), known_bits=np.zeros(2048, np.uint8))
+    rs = np.random.RandomState(0)
+    nb = Fake.cfg.bits_per_frame                       # 3*5*2 = 30 bits -> 4 bytes per frame
+    bits = rs.randint(0, 2, (7, nb)).astype(np.uint8)
+    packed = torch.from_numpy(np.packbits(bits, axis=1))
+    got = Engine.unpack_bits(Fake, packed).numpy()
+    assert np.array_equal(got, bits.reshape(-1))
