@@ -52,10 +52,14 @@ def all_gather_bits(local_bits: torch.Tensor, F_total: int | None = None, out: t
             out = torch.empty((local_bits.shape[0] * world, row), dtype=torch.uint8, device=local_bits.device)
         dist.all_gather_into_tensor(out, local_bits.contiguous())
         return out
-    sizes = [shard_range(F_total, r, world) for r in range(world)]
-    parts = [torch.empty((hi - lo, row), dtype=torch.uint8, device=local_bits.device) for lo, hi in sizes]
-    dist.all_gather(parts, local_bits.contiguous())
-    return torch.cat(parts, dim=0)
+    # ragged split: pad every shard to the largest one, still a single collective, then trim
+    sizes = [hi - lo for lo, hi in (shard_range(F_total, r, world) for r in range(world))]
+    mx = max(sizes)
+    padded = torch.zeros((mx, row), dtype=torch.uint8, device=local_bits.device)
+    padded[: local_bits.shape[0]] = local_bits
+    buf = torch.empty((world * mx, row), dtype=torch.uint8, device=local_bits.device)
+    dist.all_gather_into_tensor(buf, padded)
+    return torch.cat([buf[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
 
 
 def barrier():
