@@ -204,9 +204,6 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     };
     GF3_STAMP(0);
     if constexpr (!SPECTRA) fetch(0);
-    cplx ik[8];                                       // 1/known for this thread's carriers
-#pragma unroll
-    for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
 
     // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451)
     cplx Hs[8], He[8];
@@ -238,6 +235,9 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     double a0[8], da[8], p0[8], p1[8];
     const double invP = 1.0 / (double)P;
     tq = launder(tid);
+    cplx ik[8];                                       // 1/known for this thread's carriers
+#pragma unroll
+    for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int bn = bin_of(s);
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
             const int ps = pos_of(s);
             if constexpr (MODE == MODE_QPSK) {
                 if (ps >= 0) lab_l[ps] = (uint8_t)qpsk_sign_rule(ep);
+                if (s & 1) __builtin_amdgcn_sched_barrier(0);   // two carriers at a time: bounds the loads in flight
             } else {
                 const double mag = fma(da[s], fl, a0[s]);
                 const cplx e = cscale(ep, rcp_nr(mag));
