@@ -253,3 +253,51 @@ def test_config1_64_frames():
     assert peaks.numel() == F + 1
     o = eng.demod_frames(x, (peaks + 2)[:-1])
     assert np.array_equal(eng.unpack_bits(o["bits"]).cpu().numpy(), unpack(g))
+
+
+def test_config3_16qam_gr5_stream():
+    """BASELINE config 3 geometry: 16-QAM, N=4096/CP=512, stream through the measured 30-tap channel
+    (Handouts/gr5channel.csv, carried in the g3 fixture), stream-mode chirp sync + LS pilot equalise;
+    decoded bits and BER identical to the oracle (the reference gives BER 1.1e-3 here at F=2, g3)."""
+    from scipy.signal import lfilter
+    g = load("g3_n4096_16qam_gr5")
+    p = params_of(g, D=8)
+    F = 24
+    rs = np.random.RandomState(33)
+    payload = rs.randint(0, 2, F * p.D * p.C * p.mu)
+    fill = g["fill"]
+    r = orc.tx_stream(payload, fill, p, gaps=rs.randint(0, 300, F), lead=50, tail=40)
+    r = lfilter(g["channel"], 1.0, r) + 2e-4 * rs.randn(len(r))
+    ref = orc.receive(r, p)
+    assert len(ref["starts"]) == F
+    eng = engine_for(p, in_dtype=torch.float32)
+    x = torch.from_numpy(r.astype(np.float32)).cuda()
+    ref32 = orc.receive(r.astype(np.float32).astype(np.float64), p)
+    peaks = eng.sync_stream(x)
+    assert np.array_equal(peaks.cpu().numpy(), np.flatnonzero(ref32["zeros"]))
+    o = eng.demod_frames(x, (peaks + 2)[:-1])                       # MODE_SCAN: bits only, literal 16-point scan
+    bits = eng.unpack_bits(o["bits"]).cpu().numpy()
+    assert np.array_equal(bits, ref32["bits"])
+    ber_gpu, ber_ref = np.mean(bits != payload), np.mean(ref32["bits"] != payload)
+    assert ber_gpu == ber_ref and 0 < ber_gpu < 0.05
+    o2 = eng.demod_frames(x, (peaks + 2)[:-1], want=("eq",))          # MODE_FULL agrees with the lean mode
+    assert torch.equal(o2["bits"], o["bits"])
+    assert np.abs(o2["eq"].cpu().numpy() - ref32["eq"]).max() <= 1e-9 * max(1, np.abs(ref32["eq"]).max())
+
+
+def test_lean_modes_agree_with_full_on_noisy_qpsk():
+    """MODE_QPSK (sign rule, no magnitudes) == MODE_FULL (literal scan on equalised symbols) on noisy data,
+    and an all-zero packet (exact ties everywhere) decodes as the reference's argmin does: label 00."""
+    for name in ("g7_n4096_qpsk_drift", "g8_n4096_qpsk_gr5_drift"):
+        g = load(name)
+        p = params_of(g)
+        eng = engine_for(p)
+        x = torch.from_numpy(g["r"]).cuda()
+        starts = torch.from_numpy(g["peaks"][:-1] + 2).cuda()
+        lean = eng.demod_frames(x, starts)["bits"]
+        full = eng.demod_frames(x, starts, want=("eq", "Hest"))["bits"]
+        assert torch.equal(lean, full)
+        assert np.array_equal(eng.unpack_bits(lean).cpu().numpy(), unpack(g))
+    z = torch.zeros(200000, dtype=torch.float64, device="cuda")
+    o = eng.demod_frames(z, [1000])
+    assert int(o["bits"].sum()) == 0
