@@ -44,6 +44,51 @@ def shard_range(F_total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def cyclic_frame_index(rank: int, world: int, F_local: int, chunks: int):
+    """Global frame numbers owned by `rank` under the block-cyclic sharding the overlapped gather
+    uses: the batch is cut into `chunks` pieces of world*Fc frames, rank r owning block r of each
+    piece, so a plain all_gather_into_tensor of chunk c lands in global frame order
+    [c*world*Fc, (c+1)*world*Fc).  Returns int64 [F_local]."""
+    assert F_local % chunks == 0
+    Fc = F_local // chunks
+    c = torch.arange(chunks).repeat_interleave(Fc)
+    i = torch.arange(Fc).repeat(chunks)
+    return c * (world * Fc) + rank * Fc + i
+
+
+class OverlappedGather:
+    """One all-gather per chunk on a side stream, issued as soon as the chunk's bits exist, so
+    the xGMI transfer of chunk c runs under the kernels of chunk c+1.  `out` is [world*F_local, row]
+    in the global order of cyclic_frame_index()."""
+
+    def __init__(self, out: torch.Tensor, F_local: int, chunks: int):
+        self.out, self.F, self.chunks = out, F_local, chunks
+        self.Fc = F_local // chunks
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.side = torch.cuda.Stream() if out.is_cuda else None
+        self.works = []
+
+    def chunk_done(self, c: int, local_bits_chunk: torch.Tensor):
+        if self.world == 1:
+            return
+        dst = self.out[c * self.world * self.Fc: (c + 1) * self.world * self.Fc]
+        if self.side is None:
+            dist.all_gather_into_tensor(dst, local_bits_chunk)
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            self.works.append(dist.all_gather_into_tensor(dst, local_bits_chunk, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
 def all_gather_bits(local_bits: torch.Tensor, F_total: int | None = None, out: torch.Tensor | None = None):
     """local_bits: [F_local, bytes_per_frame] uint8 -> [F_total, bytes_per_frame] on every rank,
     frames in global order.  Equal shards use a single all_gather_into_tensor."""

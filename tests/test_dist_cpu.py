@@ -30,6 +30,17 @@ for F_total in (8, 5, 2, 3):
         out = torch.empty((F_total, row), dtype=torch.uint8)
         gd.all_gather_bits(mine, out=out)
         assert torch.equal(out, rows_of(0, F_total))
+# block-cyclic sharding + per-chunk gathers (the overlapped path of bench.py), CPU tensors
+F_local, chunks = 12, 3
+mine = gd.cyclic_frame_index(rank, world, F_local, chunks)
+local = rows_of(0, world * F_local)[mine]
+out = torch.empty((world * F_local, row), dtype=torch.uint8)
+og = gd.OverlappedGather(out, F_local, chunks)
+Fc = F_local // chunks
+for c in range(chunks):
+    og.chunk_done(c, local[c * Fc:(c + 1) * Fc].contiguous())
+og.finish()
+assert torch.equal(out, rows_of(0, world * F_local))
 t = gd.max_over_ranks(float(rank + 1), torch.device("cpu"))
 assert t == 2.0
 gd.barrier()
@@ -68,6 +79,17 @@ def test_all_gather_bits_two_ranks_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_cyclic_frame_index_covers_every_frame_once():
+    import torch
+    from gf3_audio_modem_amd.dist import cyclic_frame_index
+    for world, F_local, chunks in ((1, 8, 4), (2, 12, 3), (8, 16, 4)):
+        idx = torch.cat([cyclic_frame_index(r, world, F_local, chunks) for r in range(world)])
+        assert sorted(idx.tolist()) == list(range(world * F_local))
+        # chunk c of rank r is a contiguous block placed at c*world*Fc + r*Fc
+        Fc = F_local // chunks
+        assert cyclic_frame_index(1 % world, world, F_local, chunks)[Fc].item() == world * Fc + (1 % world) * Fc
 
 
 def test_single_process_is_identity():
