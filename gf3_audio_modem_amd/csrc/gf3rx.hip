@@ -139,7 +139,15 @@ GF3_DEV uint32_t qpsk_sign_rule(cplx e) {
 //             (1-f)|Hs| + f|He| is positive, so X/Hest and X*conj(u*rot) have the same signs and
 //             the decision needs neither the division nor |Hs|, |He|: per-carrier state is u alone.
 enum { MODE_FULL = 0, MODE_SCAN = 1, MODE_QPSK = 2 };
-template <int NC, int MODE> struct DemodOcc { static constexpr int WPS = 2; };
+#ifndef GF3_DEMOD_WPS
+#define GF3_DEMOD_WPS 2
+#endif
+// lean modes at GF3_DEMOD_WPS waves/SIMD; 3 needs the single in-place FFT buffer to fit 3 workgroups of LDS
+template <int NC, int MODE> struct DemodOcc {
+    static constexpr int WPS = (MODE != MODE_FULL && NC <= 2048) ? GF3_DEMOD_WPS : 2;
+    static constexpr bool PP = FftGeom<NC>::PINGPONG && WPS <= 2;
+    static constexpr int LDS_ELEMS = PP ? FftGeom<NC>::LDS_ELEMS : FftGeom<NC>::LDS_ELEMS_INPLACE;
+};
 
 template <int NC, int DT, bool SPECTRA, int MODE>
 __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kernel(DemodArgs a) {
@@ -147,9 +155,9 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     extern __shared__ double2 smem[];
     constexpr int T = NC / 8;
     cplx* lds = smem;
-    double* scratch = (double*)(smem + FftGeom<NC>::LDS_ELEMS);           // 32 doubles
-    cplx* rtab = (cplx*)(scratch + 32);                                   // [2][64 + NC/64 + 1] rotation tables
-    uint8_t* labs = (uint8_t*)(rtab + 2 * (64 + NC / 64 + 1));            // [2][C] decisions, one byte each
+    double* scratch = (double*)(smem + DemodOcc<NC, MODE>::LDS_ELEMS);    // 32 doubles
+    cplx* rtab = (cplx*)(scratch + 32);                                   // [3][64 + NC/64 + 1] rotation tables
+    uint8_t* labs = (uint8_t*)(rtab + 3 * (64 + NC / 64 + 1));            // [2][C] decisions, one byte each
     const int tid = threadIdx.x;
     const int64_t f = blockIdx.x;
     const int K = a.K, P = a.P, D = a.D, S = a.S;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (i + 1 < Msym) fetch(i + 1);
         tq = launder(tid);
-        rfft_regs<NC>(v, lds, ft, wb, tq, z0, i & 1);
+        rfft_regs<NC, DemodOcc<NC, MODE>::PP>(v, lds, ft.fresh(), cmk(launder(wb.x), launder(wb.y)), tq, z0, i & 1);
     };
     auto load_spectra = [&](const cplx* sp) {         // SPECTRA mode: slots straight from memory
         tq = launder(tid);
@@ -341,16 +349,26 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     };
     const double denom = (double)(D + P);
     const double qq = a.qpsk_q;
-    // two-level table of carrier-index rotations exp(j phi n), rebuilt per data symbol by the
-    // first 64+NC/64+1 threads:  n + 1 = 64 h + i  ->  rot(n) = TH[h] * TL[i],
-    // TL[i] = exp(j phi (i-1)), TH[h] = exp(j phi 64 h).  Double-buffered on l & 1.
-    constexpr int NTH = NC / 64 + 1;
-    auto build_rot = [&](int l) {
-        const double phi_l = slope * (((double)l + 0.5 * (double)P) / denom);
-        cplx* tb = rtab + (l & 1) * (64 + NTH);
-        // built by the upper half of the block: the lower half packs the previous symbol's bits
-        for (int i = (launder(tid) + T / 2) % T; i < 64 + NTH; i += T)
-            tb[i] = cis_fast(phi_l * (double)(i < 64 ? i - 1 : 64 * (i - 64)));
+    // Two-level table of carrier-index rotations exp(j phi_l n):  n + 1 = 64 h + i  ->
+    // rot(n) = TH[h] * TL[i],  TL[i] = exp(j phi (i-1)),  TH[h] = exp(j phi 64 h).
+    // phi_l = slope (l + P/2)/(D+P) is linear in l, so the table of symbol l is the table of
+    // symbol l-1 times a fixed per-packet step table (no sin/cos inside the symbol loop).
+    // rtab: [cur 0][cur 1][step], double-buffered on l & 1 (readers of l-1 may still be running).
+    constexpr int NTH = NC / 64 + 1, NRT = 64 + NTH;
+    {
+        const double phi0 = slope * ((0.5 * (double)P) / denom), dphi = slope / denom;
+        for (int i = launder(tid); i < NRT; i += T) {
+            const double nn = (double)(i < 64 ? i - 1 : 64 * (i - 64));
+            rtab[i] = cis_fast(phi0 * nn);
+            rtab[2 * NRT + i] = cis_fast(dphi * nn);
+        }
+    }
+    auto build_rot = [&](int l) {                     // table for symbol l (l >= 1) from symbol l-1
+        if (l == 0) return;
+        const cplx* prev = rtab + ((l - 1) & 1) * NRT;
+        cplx* cur = rtab + (l & 1) * NRT;
+        // done by the upper half of the block: the lower half packs the previous symbol's bits
+        for (int i = (launder(tid) + T / 2) % T; i < NRT; i += T) cur[i] = cmul(prev[i], rtab[2 * NRT + i]);
     };
     auto rot_of = [&](const cplx* tb, int n) {
         const int n1 = n + 1;
@@ -362,7 +380,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         else transform(2 * P + l);
         if (l > 0) pack_words(l - 1, false);
         const double fl = ((double)l + 0.5 * (double)P) / denom;          // (l + P/2)/(D+P)
-        const cplx* tb = rtab + (l & 1) * (64 + NTH);
+        const cplx* tb = rtab + (l & 1) * NRT;
         uint8_t* lab_l = labs + (l & 1) * C;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -474,7 +492,7 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (q + 1 < a.Q) fetch(q + 1);
         const int tq = launder(tid);
-        rfft_regs<NC, PP>(v, lds, ft, wb, tq, z0, q & 1);
+        rfft_regs<NC, PP>(v, lds, ft.fresh(), cmk(launder(wb.x), launder(wb.y)), tq, z0, q & 1);
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[s] = cadd(acc[s], cmul_conj(v[s], Hq[Spec<NC>::bin(tq, s)]));
         if (tid == 0) {
@@ -912,8 +930,9 @@ extern "C" int gf3_rfft_batch(gf3_ctx* c, const void* d_in, int64_t n_in, const 
     return GF3_OK;
 }
 
-static size_t demod_lds_bytes(const gf3_ctx* c) {
-    return fft_lds_bytes(c->NC) + 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) +
+static size_t demod_lds_bytes(const gf3_ctx* c, bool lean = false) {
+    const bool inplace = lean && GF3_DEMOD_WPS > 2 && c->NC <= 2048;
+    return (inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC)) + 32 * sizeof(double) + (size_t)3 * (64 + c->NC / 64 + 1) * sizeof(cplx) +
            (size_t)((2 * c->cfg.C + 15) & ~15);
 }
 
@@ -933,9 +952,9 @@ extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, cons
     if (d_eq || d_Hest) {
         DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_FULL>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
     } else if (c->qpsk_q > 0.0) {
-        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_QPSK>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_QPSK>), F, NCC / 8, demod_lds_bytes(c, true), (hipStream_t)stream, a));
     } else {
-        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_SCAN>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_SCAN>), F, NCC / 8, demod_lds_bytes(c, true), (hipStream_t)stream, a));
     }
     HIPCHK(c, e);
     return GF3_OK;

@@ -49,6 +49,7 @@ GF3_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::
 // Opaque copy of a per-thread index.  Everything derived from the copy is recomputed where it
 // is used instead of being hoisted out of the symbol loop and kept live (or spilled) across it.
 GF3_DEV int launder(int x) { asm volatile("" : "+v"(x)); return x; }
+GF3_DEV double launder(double x) { asm volatile("" : "+v"(x)); return x; }
 
 enum { DT_F64 = 0, DT_F32 = 1, DT_I16 = 2, DT_U8 = 3 };
 
@@ -147,7 +148,15 @@ template <int NC> struct FftGeom {
 // Per-thread twiddle bases: the index k of every pass depends only on the thread,
 // so one unit twiddle per pass is loaded once per workgroup and kept in registers.
 template <int NC> struct FftTw {
-    cplx b2, b3, b4, c4;      // c4: step to the second butterfly of a 2-butterfly pass, or (fused
+    cplx b2, b3, b4, c4;
+    // Opaque copy, taken once per transform: without it LLVM hoists every twiddle POWER
+    // (w^2..w^7 of each pass, ~80 VGPRs) out of the symbol loop and keeps them live across it.
+    GF3_DEV FftTw fresh() const {
+        FftTw f;
+        f.b2 = cmk(launder(b2.x), launder(b2.y)); f.b3 = cmk(launder(b3.x), launder(b3.y));
+        f.b4 = cmk(launder(b4.x), launder(b4.y)); f.c4 = cmk(launder(c4.x), launder(c4.y));
+        return f;
+    }      // c4: step to the second butterfly of a 2-butterfly pass, or (fused
                               // sizes) the base twiddle of the mirrored butterfly of the last pass
     GF3_DEV void init(int tid, const cplx* __restrict__ tw);
 };
