@@ -177,7 +177,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
-    const cplx wb = a.t.twn[tid];
+    cplx wb = a.t.twn[tid];
     int tq = tid;                                     // re-laundered copy of tid, refreshed per symbol
     auto bin_of = [&](int s) { return Spec<NC>::bin(tq, s); };
     auto live_of = [&](int s) { return Spec<NC>::live(tq, s); };
@@ -203,7 +203,9 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (i + 1 < Msym) fetch(i + 1);
         tq = launder(tid);
-        rfft_regs<NC, DemodOcc<NC, MODE>::PP>(v, lds, ft.fresh(), cmk(launder(wb.x), launder(wb.y)), tq, z0, i & 1);
+        ft.refresh();
+        asm volatile("" : "+v"(wb.x), "+v"(wb.y));
+        rfft_regs<NC, DemodOcc<NC, MODE>::PP>(v, lds, ft, wb, tq, z0, i & 1);
     };
     auto load_spectra = [&](const cplx* sp) {         // SPECTRA mode: slots straight from memory
         tq = launder(tid);
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
 
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
-    const cplx wb = a.t.twn[tid];
+    cplx wb = a.t.twn[tid];
     cplx acc[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc[s] = cmk(0.0, 0.0);
@@ -492,7 +494,9 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (q + 1 < a.Q) fetch(q + 1);
         const int tq = launder(tid);
-        rfft_regs<NC, PP>(v, lds, ft.fresh(), cmk(launder(wb.x), launder(wb.y)), tq, z0, q & 1);
+        ft.refresh();
+        asm volatile("" : "+v"(wb.x), "+v"(wb.y));
+        rfft_regs<NC, PP>(v, lds, ft, wb, tq, z0, q & 1);
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[s] = cadd(acc[s], cmul_conj(v[s], Hq[Spec<NC>::bin(tq, s)]));
         if (tid == 0) {

@@ -149,13 +149,12 @@ template <int NC> struct FftGeom {
 // so one unit twiddle per pass is loaded once per workgroup and kept in registers.
 template <int NC> struct FftTw {
     cplx b2, b3, b4, c4;
-    // Opaque copy, taken once per transform: without it LLVM hoists every twiddle POWER
+    // Made opaque once per transform: without it LLVM hoists every twiddle POWER
     // (w^2..w^7 of each pass, ~80 VGPRs) out of the symbol loop and keeps them live across it.
-    GF3_DEV FftTw fresh() const {
-        FftTw f;
-        f.b2 = cmk(launder(b2.x), launder(b2.y)); f.b3 = cmk(launder(b3.x), launder(b3.y));
-        f.b4 = cmk(launder(b4.x), launder(b4.y)); f.c4 = cmk(launder(c4.x), launder(c4.y));
-        return f;
+    // (in place: the empty asm "redefines" the registers it is given, no copies are made)
+    GF3_DEV void refresh() {
+        asm volatile("" : "+v"(b2.x), "+v"(b2.y), "+v"(b3.x), "+v"(b3.y));
+        asm volatile("" : "+v"(b4.x), "+v"(b4.y), "+v"(c4.x), "+v"(c4.y));
     }      // c4: step to the second butterfly of a 2-butterfly pass, or (fused
                               // sizes) the base twiddle of the mirrored butterfly of the last pass
     GF3_DEV void init(int tid, const cplx* __restrict__ tw);
