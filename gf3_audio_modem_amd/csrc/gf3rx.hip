@@ -14,6 +14,16 @@
 // ============================================================================
 // kernel argument blocks
 // ============================================================================
+// Grid constellation whose bit labels split per axis (square Gray QAM, the reference QPSK):
+// point = lvI[a] + j lvQ[b], label = labI[a] | labQ[b].  Distances then separate per axis, so
+// hard decisions and max-log LLRs cost O(levels) instead of O(points).  n = 0: not separable.
+struct SepTab {
+    int nI, nQ;
+    double lvI[8], lvQ[8];
+    int labI[8], labQ[8];       // label bits contributed by each level (already in label position)
+    int maskI;                  // label bits owned by the I axis
+};
+
 struct FftTables {
     const cplx* tw;    // [NC]      exp(-2 pi i m / NC)
     const cplx* twn;   // [NC/2+1]  exp(-2 pi i k / N)
@@ -43,6 +53,7 @@ struct DemodArgs {
     const cplx* sp_end;       // [F, P, K]
     cplx* eq_all;             // [F*D, K] equalised symbols on all carriers
     double qpsk_q;            // >0: table is the reference QPSK table (+-q +-qj): decide by signs away from ties
+    SepTab sep;
     unsigned long long* stamps;   // diagnostic build only (-DGF3_STAMPS): [F][8] s_memtime per phase
 };
 
@@ -131,6 +142,40 @@ GF3_DEV uint32_t qpsk_sign_rule(cplx e) {
     const uint32_t b1 = e.x < 0.0 ? 1u : 0u;
     const uint32_t b0 = (e.y < 0.0 || (e.y == 0.0 && e.x < 0.0)) ? 2u : 0u;
     return fin ? (b0 | b1) : 0u;
+}
+
+// Nearest level on one axis with the margin to the runner-up; first minimum wins like argmin.
+GF3_DEV int sep_axis(double x, const double* lv, int n, bool& clear) {
+    double d0 = (x - lv[0]) * (x - lv[0]), d1 = INFINITY;
+    int best = 0;
+    for (int i = 1; i < n; ++i) {
+        const double d = (x - lv[i]) * (x - lv[i]);
+        if (d < d0) { d1 = d0; d0 = d; best = i; } else if (d < d1) d1 = d;
+    }
+    clear = (d1 - d0) > 1e-9 * (d1 + d0);       // false also for NaN / Inf inputs
+    return best;
+}
+// literal first-minimum scan over the whole table (OFDM.py:493-496)
+GF3_DEV int scan_table(cplx e, const double* cre, const double* cim, int M) {
+    int best = 0;
+    double dx = e.x - cre[0], dy = e.y - cim[0];
+    double bd = dx * dx + dy * dy;
+    for (int c = 1; c < M; ++c) {
+        dx = e.x - cre[c]; dy = e.y - cim[c];
+        const double d = dx * dx + dy * dy;
+        if (d < bd) { bd = d; best = c; }
+    }
+    return best;
+}
+// hard decision -> label: per-axis when the table separates and neither axis is near a tie
+GF3_DEV uint32_t decide_label(cplx e, const SepTab& sp, const double* cre, const double* cim, const int* clab, int M) {
+    if (sp.nI > 0) {
+        bool ci, cq;
+        const int a = sep_axis(e.x, sp.lvI, sp.nI, ci);
+        const int b = sep_axis(e.y, sp.lvQ, sp.nQ, cq);
+        if (ci && cq) return (uint32_t)(sp.labI[a] | sp.labQ[b]);
+    }
+    return (uint32_t)clab[scan_table(e, cre, cim, M)];
 }
 
 // MODE_FULL : per-symbol dumps (eq, eq_all, Hest) + literal table scan on the equalised symbol
@@ -406,17 +451,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
                 if (ps >= 0) {
                     uint32_t lab;
                     if (qq > 0.0) lab = qpsk_scan(e, qq);
-                    else {                                                 // literal table scan (OFDM.py:493-496)
-                        int best = 0;
-                        double dx = e.x - a.cre[0], dy = e.y - a.cim[0];
-                        double bd = dx * dx + dy * dy;
-                        for (int c = 1; c < a.M; ++c) {
-                            dx = e.x - a.cre[c]; dy = e.y - a.cim[c];
-                            const double d = dx * dx + dy * dy;
-                            if (d < bd) { bd = d; best = c; }
-                        }
-                        lab = (uint32_t)a.clab[best];
-                    }
+                    else lab = decide_label(e, a.sep, a.cre, a.cim, a.clab, a.M);
                     lab_l[ps] = (uint8_t)lab;
                 }
             }
@@ -658,37 +693,52 @@ struct DemapArgs {
     const cplx* sym; int64_t n; int M, mu;
     const double* cre; const double* cim; const int* clab;
     uint8_t* bits; float* llr; double inv_nv; uint8_t* idx;
+    SepTab sep;
 };
 __global__ void demap_hard_kernel(DemapArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
         const cplx e = a.sym[i];
-        int best = 0;
-        double dx = e.x - a.cre[0], dy = e.y - a.cim[0];
-        double bd = dx * dx + dy * dy;
-        for (int c = 1; c < a.M; ++c) {
-            dx = e.x - a.cre[c]; dy = e.y - a.cim[c];
-            const double d = dx * dx + dy * dy;
-            if (d < bd) { bd = d; best = c; }
-        }
+        const int best = scan_table(e, a.cre, a.cim, a.M);          // literal: this entry point is `demap` itself
         const int lab = a.clab[best];
         for (int b = 0; b < a.mu; ++b) a.bits[i * a.mu + b] = (lab >> (a.mu - 1 - b)) & 1;
         if (a.idx) a.idx[i] = (uint8_t)best;
     }
 }
+// max-log LLR per bit: (min over points with bit=1 of d^2 - min over points with bit=0 of d^2) / noise_var
 __global__ void soft_demap_kernel(DemapArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
         const cplx e = a.sym[i];
         double m0[8], m1[8];
-        for (int b = 0; b < 8; ++b) m0[b] = m1[b] = INFINITY;
-        for (int c = 0; c < a.M; ++c) {
-            const double dx = e.x - a.cre[c], dy = e.y - a.cim[c];
-            const double d = dx * dx + dy * dy;
-            const int lab = a.clab[c];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                if (b < a.mu) {
-                    if ((lab >> (a.mu - 1 - b)) & 1) m1[b] = fmin(m1[b], d); else m0[b] = fmin(m0[b], d);
-                }
+        for (int b = 0; b < 8; ++b) m0[b] = m1[b] = INFINITY;
+        if (a.sep.nI > 0) {
+            // separable table: a bit owned by one axis sees the other axis' term cancel in the difference
+            for (int k = 0; k < a.sep.nI; ++k) {
+                const double d = (e.x - a.sep.lvI[k]) * (e.x - a.sep.lvI[k]);
+                const int lab = a.sep.labI[k];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (b < a.mu && ((a.sep.maskI >> (a.mu - 1 - b)) & 1)) {
+                        if ((lab >> (a.mu - 1 - b)) & 1) m1[b] = fmin(m1[b], d); else m0[b] = fmin(m0[b], d);
+                    }
+            }
+            for (int k = 0; k < a.sep.nQ; ++k) {
+                const double d = (e.y - a.sep.lvQ[k]) * (e.y - a.sep.lvQ[k]);
+                const int lab = a.sep.labQ[k];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (b < a.mu && !((a.sep.maskI >> (a.mu - 1 - b)) & 1)) {
+                        if ((lab >> (a.mu - 1 - b)) & 1) m1[b] = fmin(m1[b], d); else m0[b] = fmin(m0[b], d);
+                    }
+            }
+        } else {
+            for (int c = 0; c < a.M; ++c) {
+                const double dx = e.x - a.cre[c], dy = e.y - a.cim[c];
+                const double d = dx * dx + dy * dy;
+                const int lab = a.clab[c];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (b < a.mu) { if ((lab >> (a.mu - 1 - b)) & 1) m1[b] = fmin(m1[b], d); else m0[b] = fmin(m0[b], d); }
             }
         }
 #pragma unroll
@@ -712,6 +762,7 @@ struct gf3_ctx {
     double *d_cre = nullptr, *d_cim = nullptr;
     CorrPlan frames_plan, stream_plan;
     double qpsk_q = 0.0;
+    SepTab sep{};
     unsigned long long* stamps = nullptr;
     int contig_lo = 0;
     std::vector<double> chirp;
@@ -863,6 +914,39 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
         for (int b = 0; b < cfg->mu; ++b) lab = (lab << 1) | (cfg->const_bits[m * cfg->mu + b] & 1);
         clab[m] = lab;
     }
+    // separable grid? distinct re / im levels, full grid, every label bit a function of one axis only
+    {
+        SepTab& sp = c->sep;
+        sp.nI = sp.nQ = 0; sp.maskI = 0;
+        std::vector<double> li, lq;
+        auto find = [](std::vector<double>& v, double x) { for (size_t i = 0; i < v.size(); ++i) if (v[i] == x) return (int)i; v.push_back(x); return (int)v.size() - 1; };
+        std::vector<int> ai(cfg->M), aq(cfg->M);
+        for (int m = 0; m < cfg->M; ++m) { ai[m] = find(li, cfg->const_re[m]); aq[m] = find(lq, cfg->const_im[m]); }
+        bool ok = li.size() <= 8 && lq.size() <= 8 && (int)(li.size() * lq.size()) == cfg->M;
+        std::vector<int> seen(64, 0);
+        for (int m = 0; ok && m < cfg->M; ++m) { int& sflag = seen[ai[m] * 8 + aq[m]]; if (sflag) ok = false; sflag = 1; }
+        std::vector<int> lI(8, -1), lQ(8, -1);
+        int maskI = 0, maskQ = 0;
+        for (int b = 0; ok && b < cfg->mu; ++b) {
+            const int bit = 1 << (cfg->mu - 1 - b);
+            bool byI = true, byQ = true;
+            std::vector<int> vi(8, -1), vq(8, -1);
+            for (int m = 0; m < cfg->M; ++m) {
+                const int v = (clab[m] & bit) ? 1 : 0;
+                if (vi[ai[m]] < 0) vi[ai[m]] = v; else if (vi[ai[m]] != v) byI = false;
+                if (vq[aq[m]] < 0) vq[aq[m]] = v; else if (vq[aq[m]] != v) byQ = false;
+            }
+            if (byI) maskI |= bit; else if (byQ) maskQ |= bit; else ok = false;
+        }
+        if (ok) {
+            sp.nI = (int)li.size(); sp.nQ = (int)lq.size(); sp.maskI = maskI;
+            for (int i = 0; i < 8; ++i) { sp.lvI[i] = sp.lvQ[i] = 0; sp.labI[i] = sp.labQ[i] = 0; }
+            for (int m = 0; m < cfg->M; ++m) {
+                sp.lvI[ai[m]] = cfg->const_re[m]; sp.labI[ai[m]] = clab[m] & maskI;
+                sp.lvQ[aq[m]] = cfg->const_im[m]; sp.labQ[aq[m]] = clab[m] & maskQ;
+            }
+        }
+    }
     // the reference's QPSK table (OFDM.py:72-77): (+,+)00 (+,-)10 (-,-)11 (-,+)01 with |re|=|im|
     if (cfg->M == 4 && cfg->mu == 2) {
         const double q = cfg->const_re[0];
@@ -951,7 +1035,7 @@ extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, cons
                 c->d_known, c->d_pos, c->contig_lo, c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, (cplx*)d_eq, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, d_status,
-                nullptr, nullptr, nullptr, nullptr, c->qpsk_q, c->stamps};
+                nullptr, nullptr, nullptr, nullptr, c->qpsk_q, c->sep, c->stamps};
     hipError_t e = hipSuccess;
     if (d_eq || d_Hest) {
         DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_FULL>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
@@ -975,7 +1059,7 @@ extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start,
                 c->d_known, c->d_pos, c->contig_lo, c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, nullptr, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, nullptr,
-                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_q, nullptr};
+                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_q, c->sep, nullptr};
     hipError_t e = hipSuccess;
     switch (c->NC) {
 #ifndef GF3_DEV_BUILD
@@ -1076,7 +1160,7 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
 }
 
 static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, uint8_t* idx, float* llr, double nv, void* stream) {
-    DemapArgs a{(const cplx*)d_sym, n, c->cfg.M, c->cfg.mu, c->d_cre, c->d_cim, c->d_clab, bits, llr, nv > 0 ? 1.0 / nv : 0.0, idx};
+    DemapArgs a{(const cplx*)d_sym, n, c->cfg.M, c->cfg.mu, c->d_cre, c->d_cim, c->d_clab, bits, llr, nv > 0 ? 1.0 / nv : 0.0, idx, c->sep};
     int64_t grid = (n + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
     if (grid < 1) return GF3_OK;
