@@ -30,6 +30,7 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+WIN_LO = -8                    # search window = chirp-start lags [-8, window-8): jitter gaps 0..299 are interior points
 
 
 def build_workload(args, rank):
@@ -66,7 +67,7 @@ def cpu_baseline(cfg, rows_dev, payload, window, target_s):
         t = time.perf_counter()
         bits = []
         for s in range(0, n, nd):
-            bits.append(orc.receive_rows(rows[: min(nd, n - s)], p, 0, window)["bits"])
+            bits.append(orc.receive_rows(rows[: min(nd, n - s)], p, WIN_LO, WIN_LO + window)["bits"])
         return time.perf_counter() - t, np.concatenate(bits)
 
     ctx = threadpool_limits(limits=1) if threadpool_limits else None
@@ -120,7 +121,7 @@ def main():
         this rank's rows, then that chunk's packed bits are all-gathered on a side stream."""
         if world == 1:
             if ev: ev[0].record()
-            starts = eng.sync_frames(big, F, args.stride, 0, args.window)
+            starts = eng.sync_frames(big, F, args.stride, WIN_LO, WIN_LO + args.window)
             if ev: ev[1].record()
             eng.demod_frames(big, starts, out_bits=bits)
             if ev: ev[2].record()
@@ -128,7 +129,7 @@ def main():
         for c in range(chunks):
             rows_c = big[c * Fc:(c + 1) * Fc]
             if ev and c == 0: ev[0].record()
-            st = eng.sync_frames(rows_c, Fc, args.stride, 0, args.window)
+            st = eng.sync_frames(rows_c, Fc, args.stride, WIN_LO, WIN_LO + args.window)
             if ev and c == 0: ev[1].record()
             eng.demod_frames(rows_c, st, out_bits=bits[c * Fc:(c + 1) * Fc])
             if ev and c == 0: ev[2].record()

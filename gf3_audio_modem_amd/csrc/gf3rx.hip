@@ -748,6 +748,106 @@ __global__ void soft_demap_kernel(DemapArgs a) {
 }
 
 // ============================================================================
+// transmit-side synthesiser: one packet per workgroup
+// transmitter.map / build_OFDM_symbol / ifft / add_cp / send_to_stream (OFDM.py:196-259)
+//   row f = [gap_f zeros | chirp Lc | P known symbols | D data symbols | P known symbols | zeros]
+//   data symbol = 2 * irfft(X), X[bin] = point(label) on data carriers, filler on the others
+// ============================================================================
+struct TxArgs {
+    FftTables t;
+    int CP, S, P, D, K, C, mu, M, Lc;
+    const int* pos;               // [K] data position of a carrier or -1
+    int contig_lo;
+    const double* cre; const double* cim; const int* idx_of_label;   // label -> table index
+    const cplx* filler;           // [K] value of a non-data carrier (indexed by carrier)
+    const double* chirp;          // [Lc]
+    const double* known_time;     // [S] one pilot symbol with its prefix, before the x2 gain
+    const uint8_t* bits; int row_bytes;       // [F, row_bytes] packed payload (np.packbits order)
+    const int64_t* gaps;          // [F] leading zeros of each row (may be null)
+    void* out; int64_t stride; int out_dt;    // [F, stride] samples, f32 or f64
+};
+
+template <int NC>
+__global__ __launch_bounds__(NC / 8, 2) void tx_kernel(TxArgs a) {
+    extern __shared__ double2 smem[];
+    constexpr int T = NC / 8, N = 2 * NC;
+    cplx* lds = smem;
+    const int tid = threadIdx.x;
+    const int64_t f = blockIdx.x;
+    const int S = a.S, P = a.P, D = a.D;
+    const int64_t g = a.gaps ? a.gaps[f] : 0;
+    auto put = [&](int64_t i, double x) {
+        if (a.out_dt == DT_F32) ((float*)a.out)[f * a.stride + i] = (float)x;
+        else ((double*)a.out)[f * a.stride + i] = x;
+    };
+    const int64_t body = g + a.Lc;
+    const int64_t used = body + (int64_t)(2 * P + D) * S;
+    for (int64_t i = tid; i < a.stride; i += T) {
+        if (i < g || i >= used) put(i, 0.0);
+        else if (i < body) put(i, a.chirp[i - g]);
+    }
+    for (int p = 0; p < 2 * P; ++p) {                       // known symbols, x2 gain (OFDM.py:253-256)
+        const int64_t s0 = body + (int64_t)(p < P ? p : D + p) * S;
+        for (int i = tid; i < S; i += T) put(s0 + i, 2.0 * a.known_time[i]);
+    }
+    FftTw<NC> ft;
+    ft.init(tid, a.t.tw);
+    cplx wb = a.t.twn[tid];
+    const uint8_t* brow = a.bits + f * (int64_t)a.row_bytes;
+    auto point_of = [&](int l, int bn) -> cplx {            // value of FFT bin bn (1..K) of data symbol l
+        int ps;
+        if (a.contig_lo > 0) ps = (bn >= a.contig_lo && bn < a.contig_lo + a.C) ? bn - a.contig_lo : -1;
+        else ps = a.pos[bn - 1];
+        if (ps < 0) return a.filler[bn - 1];
+        const int o = (l * a.C + ps) * a.mu;                // first bit of the label, MSB-first stream
+        const int b0 = o >> 3, bl = a.row_bytes - 1;          // a label never extends past the row; clamp the look-ahead
+        uint32_t w = ((uint32_t)brow[b0] << 16) | ((uint32_t)brow[min(b0 + 1, bl)] << 8) | (uint32_t)brow[min(b0 + 2, bl)];
+        const uint32_t lab = (w >> (24 - a.mu - (o & 7))) & ((1u << a.mu) - 1u);
+        const int ix = a.idx_of_label[lab];
+        return cmk(a.cre[ix], a.cim[ix]);
+    };
+    for (int l = 0; l < D; ++l) {
+        const int tq = launder(tid);
+        lds_barrier();                                      // previous symbol fully written out
+        // Hermitian half-spectrum X[0..NC] (X[0] = X[NC] = 0) -> packed spectrum Z of the NC-point
+        // complex IFFT whose output interleaves even/odd samples (inverse of real_split)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = Spec<NC>::bin(tq, 2 * r);
+            const cplx A = point_of(l, k);
+            const cplx Bc = (k == NC - k) ? A : point_of(l, NC - k);
+            const cplx B = cconj(Bc);
+            const cplx E = cscale(cadd(A, B), 0.5);
+            const cplx Op = cmul_conj(cscale(csub(A, B), 0.5), Spec<NC>::pair_tw(tq, r, wb));
+            const cplx Zk = cadd(E, mul_posi(Op));
+            const cplx Zm = cadd(cconj(E), mul_posi(cconj(Op)));
+            lds[k] = cconj(Zk);
+            if (Spec<NC>::live(tq, 2 * r + 1)) lds[NC - k] = cconj(Zm);
+        }
+        if (tid == 0) lds[0] = cmk(0.0, 0.0);
+        lds_barrier();
+        cplx v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = lds[tid + r * T];
+        lds_barrier();
+        ft.refresh();
+        cplx* yb = fft_core<NC>(v, lds, ft, launder(tid));
+        // y[2n] = Re z / NC, y[2n+1] = -Im z / NC (z = conj of the forward FFT of conj Z); gain 2
+        const double sc = 2.0 / (double)NC;
+        const int64_t s0 = body + (int64_t)(P + l) * S;
+        for (int i = tid; i < NC; i += T) {
+            const cplx z = yb[i];
+            const double y0 = z.x * sc, y1 = -z.y * sc;
+            put(s0 + a.CP + 2 * i, y0);
+            put(s0 + a.CP + 2 * i + 1, y1);
+            const int j = 2 * i - (N - a.CP);               // cyclic prefix = last CP samples (OFDM.py:221-226)
+            if (j >= 0) put(s0 + j, y0);
+            if (j + 1 >= 0) put(s0 + j + 1, y1);
+        }
+    }
+}
+
+// ============================================================================
 // host side: context + C ABI
 // ============================================================================
 struct CorrPlan { int Q = 0, Lp = 0, W = 0; cplx* d_Hq = nullptr; };
@@ -762,10 +862,14 @@ struct gf3_ctx {
     double *d_cre = nullptr, *d_cim = nullptr;
     CorrPlan frames_plan, stream_plan;
     double qpsk_q = 0.0;
+    int* d_idx_of_label = nullptr;
+    double* d_chirp = nullptr;
+    double* d_known_time = nullptr;     // built on first use by gf3_tx_frames
     SepTab sep{};
     unsigned long long* stamps = nullptr;
     int contig_lo = 0;
     std::vector<double> chirp;
+    std::vector<cplx> known_pts;
     mutable char err[512];
 };
 
@@ -890,13 +994,14 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     { double sxx = 0; for (int i = 0; i < L; ++i) { const double d = i - c->xbar; sxx += d * d; } c->inv_sxx = 1.0 / sxx; }
 
     const int NC = c->NC;
-    std::vector<cplx> tw(NC), twn(NC / 2 + 1), known(K);
+    std::vector<cplx> tw(NC), twn(NC / 2 + 1), known(K), known_pts(K);
     const long double PI2 = 6.283185307179586476925286766559005768L;
     for (int m = 0; m < NC; ++m) { const long double a = -PI2 * m / NC; tw[m] = make_double2((double)cosl(a), (double)sinl(a)); }
     for (int k = 0; k <= NC / 2; ++k) { const long double a = -PI2 * k / N; twn[k] = make_double2((double)cosl(a), (double)sinl(a)); }
     for (int k = 0; k < K; ++k) {                      // 1/known = conj(known)/|known|^2
         const long double re = cfg->known_re[k], im = cfg->known_im[k], d = re * re + im * im;
         known[k] = make_double2((double)(re / d), (double)(-im / d));
+        known_pts[k] = make_double2(cfg->known_re[k], cfg->known_im[k]);
     }
     std::vector<int> pos(K, -1), clab(cfg->M);
     for (int i = 0; i < cfg->C; ++i) {
@@ -975,6 +1080,13 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     CK(upload(&c->d_known, known.data(), known.size()));
     CK(upload(&c->d_pos, pos.data(), pos.size()));
     CK(upload(&c->d_clab, clab.data(), clab.size()));
+    {
+        std::vector<int> inv(1 << cfg->mu, 0);
+        for (int m = cfg->M - 1; m >= 0; --m) inv[clab[m]] = m;
+        CK(upload(&c->d_idx_of_label, inv.data(), inv.size()));
+        CK(upload(&c->d_chirp, c->chirp.data(), c->chirp.size()));
+        c->known_pts = known_pts;
+    }
     CK(upload(&c->d_cre, cfg->const_re, (size_t)cfg->M));
     CK(upload(&c->d_cim, cfg->const_im, (size_t)cfg->M));
 #undef CK
@@ -993,7 +1105,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
 extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
     if (!c) return;
     void* ptrs[] = {c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
-                    c->frames_plan.d_Hq, c->stream_plan.d_Hq};
+                    c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_known_time};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete c;
 }
@@ -1071,6 +1183,64 @@ extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start,
     }
     HIPCHK(c, e);
     return GF3_OK;
+}
+
+// known pilot symbol in the time domain (with prefix), built with the TX kernel itself:
+// a one-symbol packet whose "filler" is the known-symbol vector and which has no data carriers.
+static int tx_launch(gf3_ctx* c, const TxArgs& a, int64_t F, hipStream_t st) {
+    const size_t lds = fft_lds_bytes(c->NC);
+    hipError_t e = hipSuccess;
+    switch (c->NC) {
+#ifndef GF3_DEV_BUILD
+        case 512:  e = launch(tx_kernel<512>, F, 64, lds, st, a); break;
+        case 1024: e = launch(tx_kernel<1024>, F, 128, lds, st, a); break;
+        case 4096: e = launch(tx_kernel<4096>, F, 512, lds, st, a); break;
+#endif
+        default:   e = launch(tx_kernel<2048>, F, 256, lds, st, a); break;
+    }
+    HIPCHK(c, e);
+    return GF3_OK;
+}
+
+extern "C" int gf3_tx_frames(gf3_ctx* c, const uint8_t* d_bits_packed, const void* d_filler_c128, const int64_t* d_gaps,
+                             int64_t F, void* d_out, int64_t stride, int32_t out_dtype, void* stream) {
+    if (c && F == 0) return GF3_OK;
+    if (!c || !d_bits_packed || !d_filler_c128 || !d_out || F < 0 || (out_dtype != GF3_F32 && out_dtype != GF3_F64))
+        return fail(c, GF3_EINVAL, "gf3_tx_frames: bad argument");
+    const gf3_config& g = c->cfg;
+    if (stride < (int64_t)c->Lc + (int64_t)(2 * g.P + g.D) * c->S) return fail(c, GF3_EINVAL, "gf3_tx_frames: stride shorter than a packet");
+    hipStream_t st = (hipStream_t)stream;
+    TxArgs a{};
+    a.t = {c->d_tw, c->d_twn};
+    a.CP = g.CP; a.S = c->S; a.K = c->K; a.mu = g.mu; a.M = g.M; a.Lc = c->Lc;
+    a.pos = c->d_pos; a.cre = c->d_cre; a.cim = c->d_cim; a.idx_of_label = c->d_idx_of_label; a.chirp = c->d_chirp;
+    if (!c->d_known_time) {
+        // one "data" symbol with zero data carriers: every bin takes the known symbol as its filler
+        cplx* d_kn = nullptr; double* d_row = nullptr; int* d_nopos = nullptr; uint8_t* d_nobits = nullptr;
+        std::vector<int> nopos(c->K, -1);
+        const int64_t rowlen = c->Lc + c->S;
+        HIPCHK(c, upload(&d_kn, c->known_pts.data(), c->known_pts.size()));
+        HIPCHK(c, upload(&d_nopos, nopos.data(), nopos.size()));
+        HIPCHK(c, hipMalloc((void**)&d_row, rowlen * sizeof(double)));
+        HIPCHK(c, hipMalloc((void**)&d_nobits, 16));
+        HIPCHK(c, hipMalloc((void**)&c->d_known_time, c->S * sizeof(double)));
+        HIPCHK(c, hipMemset(c->d_known_time, 0, c->S * sizeof(double)));
+        TxArgs k = a;
+        k.P = 0; k.D = 1; k.C = 0; k.pos = d_nopos; k.contig_lo = 0; k.filler = d_kn; k.known_time = c->d_known_time;
+        k.bits = d_nobits; k.row_bytes = 0; k.gaps = nullptr; k.out = d_row; k.stride = rowlen; k.out_dt = DT_F64;
+        int rc = tx_launch(c, k, 1, st);
+        if (rc != GF3_OK) return rc;
+        HIPCHK(c, hipStreamSynchronize(st));
+        std::vector<double> h(c->S);
+        HIPCHK(c, hipMemcpy(h.data(), d_row + c->Lc, c->S * sizeof(double), hipMemcpyDeviceToHost));
+        for (auto& x : h) x *= 0.5;                      // stored before the x2 gain
+        HIPCHK(c, hipMemcpy(c->d_known_time, h.data(), c->S * sizeof(double), hipMemcpyHostToDevice));
+        (void)hipFree(d_kn); (void)hipFree(d_row); (void)hipFree(d_nopos); (void)hipFree(d_nobits);
+    }
+    a.P = g.P; a.D = g.D; a.C = g.C; a.contig_lo = c->contig_lo; a.filler = (const cplx*)d_filler_c128;
+    a.known_time = c->d_known_time; a.bits = d_bits_packed; a.row_bytes = c->row_bytes; a.gaps = d_gaps;
+    a.out = d_out; a.stride = stride; a.out_dt = out_dtype == GF3_F32 ? DT_F32 : DT_F64;
+    return tx_launch(c, a, F, st);
 }
 
 static hipError_t run_corr(const gf3_ctx* c, const CorrArgs& a, int64_t grid, hipStream_t st) {

@@ -258,6 +258,27 @@ class Engine:
         peaks = peaks[: cnt.value]
         return (peaks, corr) if want_corr else peaks
 
+    def tx_frames(self, bits_packed, filler, stride=None, gaps=None, out_dtype=torch.float32):
+        """Synthesise chirp-prefixed packets (transmit side of the reference, OFDM.py:196-259).
+        bits_packed: uint8 [F, bytes_per_frame] (the format demod_frames writes); filler: complex [K],
+        value of every non-data carrier.  Returns [F, stride] samples: row f =
+        [gaps[f] zeros | chirp | P known symbols | D data symbols | P known symbols | zeros]."""
+        bits = torch.as_tensor(bits_packed, dtype=torch.uint8).to(self.device).contiguous()
+        if bits.dim() != 2 or bits.shape[1] != self.bytes_per_frame:
+            raise ValueError("bits_packed must be [F, bytes_per_frame]")
+        F = bits.shape[0]
+        fill = torch.as_tensor(filler, dtype=torch.complex128).to(self.device).contiguous()
+        if fill.numel() != self.cfg.K:
+            raise ValueError("filler must hold K values (one per carrier)")
+        stride = stride or self.cfg.frame_len
+        g = None if gaps is None else torch.as_tensor(gaps, dtype=torch.int64).to(self.device).contiguous()
+        if g is not None and F and int(g.max()) + self.cfg.frame_len > stride:
+            raise ValueError("gap + packet does not fit the row stride")
+        out = self._new((F, stride), out_dtype)
+        self._check(self.lib.gf3_tx_frames(self._h, _ptr(bits), _ptr(fill), _ptr(g), F, _ptr(out), stride,
+                                           _DT_OF[out_dtype], self._stream()))
+        return out
+
     def demap_hard(self, sym):
         sym = torch.as_tensor(sym, dtype=torch.complex128).to(self.device).contiguous()
         n = sym.numel()

@@ -171,6 +171,20 @@ int gf3_sync_stream(gf3_ctx *ctx, const void *d_r, int64_t n,
 int gf3_demap_hard(gf3_ctx *ctx, const void *d_sym_c128, int64_t n,
                    uint8_t *d_bits_u8, uint8_t *d_idx_u8, void *stream);
 
+/*
+ * Transmit-side synthesiser: transmitter.map + build_OFDM_symbol + ifft + add_cp +
+ * send_to_stream (OFDM.py:196-259) for F packets, one row of `stride` samples per packet:
+ *   [gap_f zeros | chirp | P known symbols | D data symbols | P known symbols | zeros], symbols x2.
+ *   d_bits_packed [F, gf3_bytes_per_frame]: payload in the format gf3_demod_frames writes
+ *   d_filler_c128 [K]: value of every carrier that is not a data carrier (random_qpsk, OFDM.py:201-215),
+ *                      indexed by carrier (entries of data carriers are ignored)
+ *   d_gaps        [F] int64 leading zeros per row, or NULL
+ *   out_dtype     GF3_F32 or GF3_F64
+ */
+int gf3_tx_frames(gf3_ctx *ctx, const uint8_t *d_bits_packed, const void *d_filler_c128,
+                  const int64_t *d_gaps, int64_t F, void *d_out, int64_t stride,
+                  int32_t out_dtype, void *stream);
+
 /* max-log soft demapping (not in the reference; LLR > 0 <=> bit 0). [n*mu] f32 */
 int gf3_soft_demap(gf3_ctx *ctx, const void *d_sym_c128, int64_t n,
                    double noise_var, float *d_llr_f32, void *stream);

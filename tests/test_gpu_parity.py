@@ -301,3 +301,50 @@ def test_lean_modes_agree_with_full_on_noisy_qpsk():
     z = torch.zeros(200000, dtype=torch.float64, device="cuda")
     o = eng.demod_frames(z, [1000])
     assert int(o["bits"].sum()) == 0
+
+
+@pytest.mark.parametrize("name", ["g1_n1024_qpsk", "g2_n4096_qpsk", "g3_n4096_16qam_gr5"])
+def test_tx_frames_matches_reference_stream(name):
+    """gf3_tx_frames against the reference's transmit() output (fixture stream r, noise-free part):
+    the rows it builds, laid out with the fixture's gaps, reproduce the stream to 1e-12."""
+    g = load(name)
+    p = params_of(g)
+    eng = engine_for(p)
+    payload = unpack(g, "payload", "n_payload")
+    F = len(payload) // (p.D * p.C * p.mu)
+    packed = orc.pack_bits(payload, p.D * p.C * p.mu)
+    filler = np.zeros(p.K, dtype=complex)
+    unused = np.delete(np.arange(1, p.K + 1), p.data_carriers - 1)
+    filler[unused - 1] = g["fill"]
+    rows = eng.tx_frames(packed, filler, out_dtype=torch.float64).cpu().numpy()
+    ref_rows = orc.tx_frames(payload, g["fill"], p)                  # bit-exact restatement of transmit()
+    assert rows.shape == ref_rows.shape == (F, p.frame_len)
+    assert np.abs(rows - ref_rows).max() <= 1e-12 * np.abs(ref_rows).max()
+    if len(g["channel"]) == 0:                                       # and hence the reference's own stream
+        r = g["r"]; pos = int(g["lead"])
+        for f in range(F):
+            pos += int(g["gaps"][f])
+            assert np.abs(r[pos: pos + p.frame_len] - rows[f]).max() <= 1e-12 * np.abs(r).max()
+            pos += p.frame_len
+
+
+def test_tx_rx_round_trip_full_size():
+    """Size-independent property at BASELINE config-2 size: TX -> (jitter gaps) -> sync -> demod returns
+    the payload for every frame; 4096 distinct frames, 64-QAM too."""
+    for mu, F in ((2, 4096), (6, 256)):
+        pts, bt = orc.qpsk_table() if mu == 2 else orc.square_qam_table(mu)
+        K = 2047
+        known = np.tile(load("g6_realrec")["known_bits"], -(-K * mu // 4096))
+        p = orc.RxParams(N=4096, CP=512, P=2, D=8, lo=1, hi=K, const_points=pts, const_bits=bt, known_bits=known)
+        eng = engine_for(p, in_dtype=torch.float32, max_window=320)
+        g = torch.Generator(device="cuda").manual_seed(mu)
+        packed = torch.randint(0, 256, (F, eng.bytes_per_frame), dtype=torch.uint8, device="cuda", generator=g)
+        gaps = torch.randint(0, 300, (F,), dtype=torch.int64, device="cuda", generator=g)
+        filler = np.zeros(K, dtype=complex); filler[K - 1] = (1 - 1j) / np.sqrt(2)
+        stride = 78720
+        rows = eng.tx_frames(packed, filler, stride=stride, gaps=gaps, out_dtype=torch.float32)
+        # the peak rule needs an interior point: start the window a few lags before the earliest chirp start
+        starts = eng.sync_frames(rows, F, stride, -8, 312)
+        assert torch.equal(starts, torch.arange(F, device="cuda") * stride + gaps + p.Lc)
+        out = eng.demod_frames(rows, starts)["bits"]
+        assert torch.equal(out, packed)
