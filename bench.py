@@ -8,7 +8,7 @@ is already resident in HBM:
  -> (N>1 only) one RCCL all-gather of the bit-packed payload.
 Workload: N=4096, CP=512, P=2, D=8, QPSK on bins 1..2046, F frames per GPU (weak
 scaling), each frame a row of `stride` fp32 samples = [jitter gap 0..299 | chirp |
-2 pilots | 8 data | 2 pilots | pad], built on device by tiling 64 distinct frames.
+2 pilots | 8 data | 2 pilots | pad], all distinct, synthesised on device by gf3_tx_frames.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -34,8 +34,10 @@ WIN_LO = -8                    # search window = chirp-start lags [-8, window-8)
 
 
 def build_workload(args, rank):
+    """F distinct frame buffers, synthesised on the device by the engine's own transmit kernel
+    (gf3_tx_frames): random payload, jitter gap 0..299 before each chirp, QPSK filler on the one
+    non-data carrier.  Returns the rows and what the receiver must recover."""
     from gf3_audio_modem_amd import Engine, RxConfig, qpsk_table
-    from gf3_audio_modem_amd import synth
     N, CP, P, D = 4096, 512, 2, 8
     K = N // 2 - 1
     pts, bt = qpsk_table()
@@ -43,14 +45,16 @@ def build_workload(args, rank):
     cfg = RxConfig(N=N, CP=CP, P=P, D=D, data_bins=np.arange(1, K), const_points=pts, const_bits=bt,
                    known_bits=known, in_dtype=torch.float32, max_window=args.window)
     eng = Engine(cfg)
-    stride = args.stride
-    rows, payload, gaps = synth.make_frames(cfg, eng.chirp_replica(), args.distinct, seed=20261003 + rank,
-                                            stride=stride, gmax=300, dtype=torch.float32)
-    big = synth.tile_rows(rows, args.frames)
-    return eng, cfg, big, payload, gaps, rows
+    gen = torch.Generator(device="cuda").manual_seed(20261003 + rank)
+    payload = torch.randint(0, 256, (args.frames, eng.bytes_per_frame), dtype=torch.uint8, device="cuda", generator=gen)
+    gaps = torch.randint(0, 300, (args.frames,), dtype=torch.int64, device="cuda", generator=gen)
+    filler = np.zeros(K, dtype=complex)
+    filler[K - 1] = pts[(20261003 + rank) % 4]                  # random_qpsk for the unused carrier (OFDM.py:201-215)
+    big = eng.tx_frames(payload, filler, stride=args.stride, gaps=gaps, out_dtype=torch.float32)
+    return eng, cfg, big, payload, gaps
 
 
-def cpu_baseline(cfg, rows_dev, payload, window, target_s):
+def cpu_baseline(cfg, rows_dev, payload_dev, window, target_s):
     """Oracle ('port' of the reference algorithm, NumPy, 1 thread) on a bounded sample of
     the same frame buffers."""
     from oracle import gf3_oracle as orc
@@ -60,25 +64,22 @@ def cpu_baseline(cfg, rows_dev, payload, window, target_s):
         threadpool_limits = None
     p = orc.RxParams(N=cfg.N, CP=cfg.CP, P=cfg.P, D=cfg.D, lo=1, hi=cfg.K, const_points=cfg.const_points,
                      const_bits=np.asarray(cfg.const_bits, dtype=np.int64), known_bits=cfg.known_bits)
-    rows = rows_dev.cpu().numpy().astype(np.float64)
-    nd = len(rows)
-
-    def run(n):                       # n frame buffers, cycling through the distinct ones like the GPU batch
-        t = time.perf_counter()
-        bits = []
-        for s in range(0, n, nd):
-            bits.append(orc.receive_rows(rows[: min(nd, n - s)], p, WIN_LO, WIN_LO + window)["bits"])
-        return time.perf_counter() - t, np.concatenate(bits)
-
     ctx = threadpool_limits(limits=1) if threadpool_limits else None
     try:
-        t4, _ = run(4)
-        n = int(max(4, target_s / (t4 / 4)))
-        dt, bits = run(n)
+        rows4 = rows_dev[:4].cpu().numpy().astype(np.float64)
+        t = time.perf_counter(); orc.receive_rows(rows4, p, WIN_LO, WIN_LO + window); t4 = time.perf_counter() - t
+        n = int(max(4, min(rows_dev.shape[0], target_s / (t4 / 4))))
+        rows = rows_dev[:n].cpu().numpy().astype(np.float64)       # the first n of the GPU batch's frame buffers
+        t = time.perf_counter()
+        bits = []
+        for s in range(0, n, 64):                                 # 64 rows at a time keeps the working set small
+            bits.append(orc.receive_rows(rows[s: s + 64], p, WIN_LO, WIN_LO + window)["bits"])
+        dt = time.perf_counter() - t
+        bits = np.concatenate(bits)
     finally:
         if ctx is not None and hasattr(ctx, "unregister"):
             ctx.unregister()
-    want = np.concatenate([payload[: min(nd, n - s)] for s in range(0, n, nd)])
+    want = np.unpackbits(payload_dev[:n].cpu().numpy(), axis=1)[:, : cfg.bits_per_frame]
     ok = bool(np.array_equal(bits.reshape(n, -1), want))
     return {"value": n * rows.shape[1] / dt, "unit": "samples/s", "cores": 1, "kind": "port",
             "sample": f"{n} config-2 frame buffers ({n * rows.shape[1]} samples) through oracle.receive_rows "
@@ -91,7 +92,6 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU")
-    ap.add_argument("--distinct", type=int, default=64)
     ap.add_argument("--stride", type=int, default=78720)
     ap.add_argument("--window", type=int, default=320)
     ap.add_argument("--chunks", type=int, default=4, help="N>1: pieces the batch is cut into to overlap the all-gather")
@@ -106,7 +106,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    eng, cfg, big, payload, gaps, rows = build_workload(args, rank)
+    eng, cfg, big, payload, gaps = build_workload(args, rank)
     F = args.frames
     n_samples = F * args.stride
     bits = torch.empty((F, eng.bytes_per_frame), dtype=torch.uint8, device=dev)
@@ -151,12 +151,13 @@ def main():
     dt = time.perf_counter() - t0
     dt = gd.max_over_ranks(dt, dev)
 
-    # correctness of what was just timed: every tiled frame decodes to its payload
-    got = eng.unpack_bits(bits[: args.distinct]).cpu().numpy().reshape(args.distinct, -1)
-    bit_errors = int((got != payload).sum())
-    exp_starts = np.arange(args.distinct) * args.stride + gaps + cfg.chirp_length
-    sync_ok = bool(np.array_equal(starts[: args.distinct].cpu().numpy(), exp_starts))
-    tail_same = bool(torch.equal(bits[-args.distinct:], bits[: args.distinct])) if F % args.distinct == 0 else None
+    # correctness of what was just timed: EVERY frame decodes to its payload, every sync offset exact
+    bit_errors = int(torch.count_nonzero(torch.bitwise_xor(bits, payload)).item())   # differing bytes (0 => BER 0)
+    if bit_errors:
+        x = torch.bitwise_xor(bits, payload).cpu().numpy()
+        bit_errors = int(np.unpackbits(x).sum())
+    exp_starts = torch.arange(F, device=dev, dtype=torch.int64) * args.stride + gaps + cfg.chirp_length
+    sync_ok = bool(torch.equal(starts, exp_starts))
     gather_ok = None
     if world > 1:       # every rank must hold every rank's bits, in the block-cyclic global order
         mine = gd.cyclic_frame_index(rank, world, F, chunks).to(dev)
@@ -193,7 +194,7 @@ def main():
                        "frames_per_gpu": F, "samples_per_frame": args.stride, "sample_storage": "f32",
                        "sync_window_lags": args.window, "parallelism": f"frames sharded over {world} GPU(s), "
                        f"packed bits all-gathered in {chunks} chunk(s) under compute" if world > 1 else "single GPU"},
-            "ber": bit_errors / payload.size, "bit_errors": bit_errors, "sync_exact": sync_ok, "tiles_identical": tail_same,
+            "ber": bit_errors / (F * cfg.bits_per_frame), "bit_errors": bit_errors, "frames_checked": F, "sync_exact": sync_ok,
             "gather_exact": gather_ok,
             "roofline": {"kernel": "demod_kernel<2048,f32,MODE_QPSK>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
@@ -203,7 +204,7 @@ def main():
                               "algorithmic_bytes_per_launch": bytes_sync, "avg_launch_ms": t_sync * 1e3},
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(cfg, rows, payload, args.window, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cfg, big, payload, args.window, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
