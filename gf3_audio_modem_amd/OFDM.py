@@ -21,7 +21,7 @@ import torch
 
 from .engine import Engine, RxConfig, map_bits
 
-__all__ = ["CamG", "receiver", "np"]
+__all__ = ["CamG", "transmitter", "receiver", "load_file", "save_file", "np"]
 
 _NP2T = {np.dtype("float64"): torch.float64, np.dtype("float32"): torch.float32,
          np.dtype("int16"): torch.int16, np.dtype("uint8"): torch.uint8}
@@ -123,7 +123,71 @@ def _as_samples(r):
     return np.ascontiguousarray(r)
 
 
-class receiver(CamG):
+class transmitter(CamG):
+    """OFDM.py:125-343.  The bit-level steps (encode/SP/map/build_OFDM_symbol/add_cp/send_to_stream)
+    keep the reference's NumPy semantics, including its use of the legacy global NumPy RNG (random
+    padding :147,172,183 and the unused-carrier filler :203) in the same call order, so a seeded run
+    reproduces the reference's stream; `transmit` runs map + IFFT + CP + framing in the HIP kernel."""
+
+    def encode(self, bits):
+        if self.encoding == "LDPC":
+            raise NotImplementedError("LDPC encoding is out of scope (pyldpc; marked broken in the reference, OFDM.py:21)")
+        if self.encoding == "XOR":                                     # OFDM.py:163-173
+            known_bits = np.tile(self.known_sequence[:self.data_bits_per_symbol],
+                                 int(np.ceil(len(bits) / self.data_bits_per_symbol)))[:len(bits)]
+            bits = np.bitwise_xor(bits, known_bits)
+        bits_per_packet = self.data_bits_per_symbol * self.packet_length
+        padding_length = (bits_per_packet - len(bits) % bits_per_packet) % bits_per_packet
+        padding = np.random.binomial(n=1, p=0.5, size=(padding_length,))   # "packing with zeros is bad"
+        return np.hstack([bits, padding])
+
+    def SP(self, bits):
+        return bits.reshape(-1, self.data_carriers_per_symbol, self.mu)
+
+    def random_qpsk(self):
+        qpsk = np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2)
+        return np.random.choice(qpsk, size=(self.K - self.data_carriers_per_symbol), replace=True)
+
+    def build_OFDM_symbol(self, payload):
+        symbols = np.zeros([payload.shape[0], self.ofdm_symbol_size], dtype=complex)
+        rand_qpsk = self.random_qpsk()
+        symbols[:, self.data_carriers] = payload
+        symbols[:, self.unused_carriers] = rand_qpsk
+        symbols[:, -self.data_carriers] = np.conj(payload)
+        symbols[:, -self.unused_carriers] = np.conj(rand_qpsk)
+        return symbols
+
+    def add_cp(self, time_data):
+        if self.cp_length == 0:
+            return time_data
+        return np.hstack([time_data[:, -self.cp_length:], time_data])
+
+    def transmit(self, bits, graph_output=False):
+        print("-" * 42 + "\nTRANSMIT\n" + "-" * 42)
+        print("OFDM Paramters:")
+        print(self)
+        bits_encoded = np.asarray(self.encode(np.asarray(bits)), dtype=np.uint8)
+        eng = self._engine()
+        nbp = self.packet_length * self.data_bits_per_symbol
+        self.no_packets = len(bits_encoded) // nbp
+        rand_qpsk = self.random_qpsk()                                  # same RNG draw build_OFDM_symbol makes
+        filler = np.zeros(self.K, dtype=complex)
+        filler[self.unused_carriers - 1] = rand_qpsk
+        print("Number of bits to transmit:         " + str(len(bits)))
+        print("Number of OFDM symbols to transmit: " + str(self.no_packets * self.packet_length))
+        packed = np.packbits(bits_encoded.reshape(self.no_packets, nbp), axis=1)
+        rows = eng.tx_frames(packed, filler, out_dtype=torch.float64)   # [packets, chirp + (2P+D)(N+CP)]
+        signal = np.hstack([rows.cpu().numpy().reshape(-1), self.sync_chirp()])     # final chirp (OFDM.py:259)
+        print("Number of packets to transmit:      " + str(self.no_packets))
+        if graph_output:
+            import matplotlib.pyplot as plt
+            time = np.linspace(0, len(signal) / self.fs, len(signal))
+            plt.plot(time, 5 * signal, label="Signal")
+            plt.title("OFDM Frame"); plt.xlabel("time"); plt.legend(); plt.savefig("OFDM Frame"); plt.show()
+        return signal
+
+
+class receiver(transmitter):
     """OFDM.py:353-657.  Stage methods keep the reference's NumPy-in/NumPy-out
     contract; `receive` runs the fused device path."""
 
@@ -272,3 +336,30 @@ class receiver(CamG):
         plt.plot(np.linspace(0, len(h), len(h))[:500], h.real[:500])
         plt.title("Channel Impulse Response"); plt.ylabel("h"); plt.xlabel("time (samples)")
         plt.savefig("plots/Channel_inpulse"); plt.show()
+
+
+# ---- file framing (OFDM.py:756-794): host I/O only -------------------------------------------------
+def load_file(file_name):
+    """name\\0size\\0 header + file bytes -> bit array (OFDM.py:756-761)."""
+    data_bytes = np.fromfile("input_files/" + file_name, dtype=np.uint8)
+    file_info = file_name + "\x00" + str(len(data_bytes)) + "\x00"
+    b = bytearray()
+    b.extend(map(ord, file_info))
+    return np.unpackbits(np.hstack([b, data_bytes]))
+
+
+def save_file(rx_bits):
+    """Inverse of load_file (OFDM.py:766-794): parse the two NUL-terminated header fields, write
+    output_files/<name>_received<ext>, return (file_name, data)."""
+    data = np.packbits(np.asarray(rx_bits).astype(np.uint8))
+    z1 = int(np.flatnonzero(data == 0)[0])
+    file_name = "".join(chr(c) for c in data[:z1])
+    rest = data[z1 + 1:]
+    z2 = int(np.flatnonzero(rest == 0)[0])
+    file_size = "".join(chr(c) for c in rest[:z2])
+    data = rest[z2 + 1:]
+    print("File Name: " + file_name + "\nFile Size: " + file_size + " bytes")
+    data = data[:int(file_size)]
+    os.makedirs("output_files", exist_ok=True)
+    data.tofile("output_files/" + file_name[:-4] + "_received" + file_name[-4:])
+    return file_name, data

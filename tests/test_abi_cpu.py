@@ -70,3 +70,19 @@ def test_tables_match_oracle():
     for mu in (4, 6):
         a, b = square_qam_table(mu), orc.square_qam_table(mu)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_load_save_file_framing(tmp_path, monkeypatch, capsys):
+    """File framing of OFDM.py:756-794 (host I/O, no GPU): name\\0size\\0 + bytes, and its inverse."""
+    from gf3_audio_modem_amd.OFDM import load_file, save_file
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "input_files").mkdir()
+    blob = np.arange(300, dtype=np.uint8)
+    blob.tofile(tmp_path / "input_files" / "abc.bmp")
+    bits = load_file("abc.bmp")
+    hdr = b"abc.bmp\x00300\x00"
+    assert np.array_equal(np.packbits(bits)[: len(hdr)], np.frombuffer(hdr, dtype=np.uint8))
+    assert len(bits) == 8 * (len(hdr) + 300)
+    name, data = save_file(np.concatenate([bits, np.ones(37, dtype=np.uint8)]))      # trailing padding is ignored
+    assert name == "abc.bmp" and np.array_equal(data, blob)
+    assert (tmp_path / "output_files" / "abc_received.bmp").exists()

@@ -348,3 +348,49 @@ def test_tx_rx_round_trip_full_size():
         assert torch.equal(starts, torch.arange(F, device="cuda") * stride + gaps + p.Lc)
         out = eng.demod_frames(rows, starts)["bits"]
         assert torch.equal(out, packed)
+
+
+def test_facade_transmitter_reproduces_seeded_reference_stream(capsys):
+    """transmitter.transmit with the same legacy-RNG seed as the fixture run gives the reference's stream."""
+    from gf3_audio_modem_amd.OFDM import transmitter
+    g = load("g2_n4096_qpsk")
+    p = params_of(g)
+    tx = transmitter(mode="A1", encoding="None", no_pilots=p.P, packet_length=p.D)
+    tx.cp_length = p.CP
+    tx.chirp_length = 5 * (p.N + p.CP)
+    tx.lowest_bin, tx.highest_bin = p.lo, p.hi
+    tx.data_carriers = np.arange(p.lo, p.hi)
+    tx.data_carriers_per_symbol = p.C
+    tx.unused_carriers = np.delete(tx.carriers, tx.data_carriers - 1)
+    tx.data_bits_per_symbol = p.C * p.mu
+    payload = unpack(g, "payload", "n_payload")
+    np.random.seed(int(g["seed"]))
+    sig = tx.transmit(payload)
+    out = capsys.readouterr().out
+    assert "Number of packets to transmit:      2" in out and "TRANSMIT" in out
+    r = g["r"]
+    ref = np.concatenate([r[int(g["lead"]) + int(g["gaps"][0]): int(g["lead"]) + int(g["gaps"][0]) + p.frame_len],
+                          r[int(g["lead"]) + int(g["gaps"][:2].sum()) + p.frame_len:][: p.frame_len + p.Lc]])
+    assert sig.shape == ref.shape
+    assert np.abs(sig - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_facade_file_round_trip(tmp_path, monkeypatch, capsys):
+    """load_file -> transmit -> receive -> save_file through the drop-in module (Final System Test flow, noiseless)."""
+    from gf3_audio_modem_amd import OFDM as M
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "input_files").mkdir()
+    blob = np.random.RandomState(4).randint(0, 256, 20000, dtype=np.uint8)
+    blob.tofile(tmp_path / "input_files" / "demo.bin")
+    bits = M.load_file("demo.bin")
+    tx = M.transmitter(mode="A2", encoding="XOR", no_pilots=2, packet_length=8)
+    np.random.seed(0)
+    s = tx.transmit(bits)
+    r = np.concatenate([np.zeros(100), s, np.zeros(50)])
+    rx = M.receiver(mode="A2", encoding="XOR", no_pilots=2, packet_length=8)
+    out_bits, Hs, He = rx.receive(r)
+    assert np.array_equal(out_bits[: len(bits)], bits)
+    name, data = M.save_file(out_bits)
+    assert name == "demo.bin" and np.array_equal(data, blob)
+    assert np.array_equal(np.fromfile(tmp_path / "output_files" / "demo_received.bin", dtype=np.uint8), blob)
+    assert "File Size: 20000 bytes" in capsys.readouterr().out
