@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
     cplx wb = a.t.twn[tid];
-    int tq = tid;                                     // re-laundered copy of tid, refreshed per symbol
+    const int tq = tid;       // 32-bit per-thread indices derived from it may be hoisted: cheap in registers
     auto bin_of = [&](int s) { return Spec<NC>::bin(tq, s); };
     auto live_of = [&](int s) { return Spec<NC>::live(tq, s); };
     auto pos_of = [&](int s) {
@@ -247,13 +247,11 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (i + 1 < Msym) fetch(i + 1);
-        tq = launder(tid);
         ft.refresh();
         asm volatile("" : "+v"(wb.x), "+v"(wb.y));
         rfft_regs<NC, DemodOcc<NC, MODE>::PP>(v, lds, ft, wb, tq, z0, i & 1);
     };
     auto load_spectra = [&](const cplx* sp) {         // SPECTRA mode: slots straight from memory
-        tq = launder(tid);
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2) v[s2] = sp[bin_of(s2) - 1];
     };
@@ -264,15 +262,18 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     cplx Hs[8], He[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) Hs[s] = He[s] = cmk(0.0, 0.0);
-    for (int i = 0; i < 2 * P; ++i) {
+    for (int i = 0; i < P; ++i) {
         if (i == 1) GF3_STAMP(1);
-        const bool side = i >= P;
-        if constexpr (SPECTRA) load_spectra((side ? a.sp_end : a.sp_start) + ((int64_t)f * P + (side ? i - P : i)) * K);
+        if constexpr (SPECTRA) load_spectra(a.sp_start + ((int64_t)f * P + i) * K);
         else transform(i);
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-            if (side) He[s2] = cadd(He[s2], v[s2]); else Hs[s2] = cadd(Hs[s2], v[s2]);
-        }
+        for (int s2 = 0; s2 < 8; ++s2) Hs[s2] = cadd(Hs[s2], v[s2]);
+    }
+    for (int i = P; i < 2 * P; ++i) {
+        if constexpr (SPECTRA) load_spectra(a.sp_end + ((int64_t)f * P + (i - P)) * K);
+        else transform(i);
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) He[s2] = cadd(He[s2], v[s2]);
     }
 
     // ---- per carrier: H = mean / known; equaliser state
@@ -289,7 +290,6 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     cplx u[8];
     double a0[8], da[8], p0[8], p1[8];
     const double invP = 1.0 / (double)P;
-    tq = launder(tid);
     cplx ik[8];                                       // 1/known for this thread's carriers
 #pragma unroll
     for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
