@@ -509,16 +509,24 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
     auto fetch = [&](int q) {
         const int64_t seg = s0 + (int64_t)q * a.Lp;
         const bool inside = seg >= 0 && seg + 2 * NC <= a.n_in;
-        const int tf = launder(tid);
+        typedef typename RawT<DT>::E E;
+        if (inside && need >= 14 * T) {
+            // common case: the segment lies inside the buffer and only the last of the eight
+            // strided loads can reach past the samples that matter (j >= need)
+            const int64_t base = seg + 2 * tid;
+#pragma unroll
+            for (int r = 0; r < 7; ++r) nxt[r].load(a.in, base + 2 * (int64_t)(r * T));
+            const int j = 2 * (tid + 7 * T);
+            if (j + 1 < need) nxt[7].load(a.in, seg + j);
+            else { nxt[7].zero(); if (j < need) nxt[7].v.a = ((const E*)a.in)[seg + j]; }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int j = 2 * (tf + r * T);
-            if (inside && j + 1 < need) nxt[r].load(a.in, seg + j);
-            else {
-                nxt[r].zero();
-                if (j < need && seg + j >= 0 && seg + j < a.n_in) nxt[r].v.a = ((const typename RawT<DT>::E*)a.in)[seg + j];
-                if (j + 1 < need && seg + j + 1 >= 0 && seg + j + 1 < a.n_in) nxt[r].v.b = ((const typename RawT<DT>::E*)a.in)[seg + j + 1];
-            }
+            const int j = 2 * (tid + r * T);
+            nxt[r].zero();
+            if (j < need && seg + j >= 0 && seg + j < a.n_in) nxt[r].v.a = ((const E*)a.in)[seg + j];
+            if (j + 1 < need && seg + j + 1 >= 0 && seg + j + 1 < a.n_in) nxt[r].v.b = ((const E*)a.in)[seg + j + 1];
         }
     };
     fetch(0);
@@ -528,7 +536,7 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (q + 1 < a.Q) fetch(q + 1);
-        const int tq = launder(tid);
+        const int tq = tid;
         ft.refresh();
         asm volatile("" : "+v"(wb.x), "+v"(wb.y));
         rfft_regs<NC, PP>(v, lds, ft, wb, tq, z0, q & 1);
