@@ -394,3 +394,31 @@ def test_facade_file_round_trip(tmp_path, monkeypatch, capsys):
     assert name == "demo.bin" and np.array_equal(data, blob)
     assert np.array_equal(np.fromfile(tmp_path / "output_files" / "demo_received.bin", dtype=np.uint8), blob)
     assert "File Size: 20000 bytes" in capsys.readouterr().out
+
+
+def test_abi_error_paths():
+    """Errors mirrored from the reference / documented in gf3rx.h: bad geometry, bad modulation,
+    fit range too short, repeated data bins, wrong buffer shapes."""
+    from gf3_audio_modem_amd import Engine, RxConfig, qpsk_table
+    pts, bt = qpsk_table()
+    known = np.zeros(8190, np.uint8)
+    ok = dict(N=1024, CP=128, P=2, D=8, data_bins=np.arange(1, 511), const_points=pts, const_bits=bt,
+              known_bits=known, fit_lo=100, fit_hi=400)
+    Engine(RxConfig(**ok)).close()
+    for bad, msg in ((dict(N=1000), "unsupported"), (dict(P=0), "P>=1"), (dict(fit_lo=509, fit_hi=510), "fit range"),
+                     (dict(data_bins=np.array([5, 5, 6])), "repeated"), (dict(data_bins=np.array([0, 1])), "invalid")):
+        with pytest.raises(ValueError, match=msg):
+            Engine(RxConfig(**{**ok, **bad}))
+    with pytest.raises(ValueError, match="Invalid Modulation"):
+        Engine(RxConfig(**{**ok, "const_points": pts[:1], "const_bits": bt[:1]}))
+    with pytest.raises(ValueError, match="known_bits"):
+        Engine(RxConfig(**{**ok, "known_bits": np.zeros(10, np.uint8)}))
+    eng = Engine(RxConfig(**ok))
+    with pytest.raises(ValueError, match="bytes_per_frame"):
+        eng.tx_frames(np.zeros((2, 3), np.uint8), np.zeros(511, complex))
+    with pytest.raises(ValueError, match="K values"):
+        eng.tx_frames(np.zeros((2, eng.bytes_per_frame), np.uint8), np.zeros(5, complex))
+    with pytest.raises(ValueError, match="stride"):
+        eng.tx_frames(np.zeros((2, eng.bytes_per_frame), np.uint8), np.zeros(511, complex), stride=100)
+    with pytest.raises(ValueError, match="shapes"):
+        eng.equalise(np.zeros((1, 8, 10), complex), np.zeros((1, 2, 511), complex), np.zeros((1, 2, 511), complex))
