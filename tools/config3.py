@@ -29,12 +29,13 @@ chirp = torch.from_numpy(eng.chirp_replica()).cuda()
 s = torch.cat([torch.zeros(64, dtype=torch.float64, device="cuda"), rows.reshape(-1), chirp,
                torch.zeros(64, dtype=torch.float64, device="cuda")])
 del rows
-# channel: causal FIR (lfilter(h, 1, s)) on the device -- input generation, not the measured path
-L = h.numel()
-sp = torch.nn.functional.pad(s.view(1, 1, -1), (L - 1, 0))
-r = torch.nn.functional.conv1d(sp, h.flip(0).view(1, 1, -1)).view(-1)
+# channel: causal FIR (lfilter(h, 1, s)) on the device as 30 shifted adds -- input generation, not the
+# measured path (torch's conv1d is not reliable at this length)
+r = torch.zeros_like(s)
+for k in range(h.numel()):
+    r[k:] += float(h[k]) * s[: s.numel() - k]
 r = (r + 2e-4 * torch.randn(r.numel(), dtype=torch.float64, device="cuda", generator=gen)).to(torch.float32)
-del s, sp
+del s
 n = r.numel()
 torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -60,7 +61,25 @@ st = starts[:m].cpu().numpy()
 ref = orc.demod_frames(seg, st, p)["bits"]
 gpu = np.unpackbits(out[:m].cpu().numpy(), axis=1)[:, : cfg.bits_per_frame].reshape(-1)
 res["first_packets_identical_to_oracle"] = bool(np.array_equal(ref, gpu))
+# per-packet error counts; the worst packets (where the reference's unwrap/slope model struggles in the
+# channel's nulls) are checked against the oracle too: parity is about matching the reference, not BER
+per = np.unpackbits(err.cpu().numpy(), axis=1).sum(axis=1)
+worst = np.argsort(per)[-3:]
+res["per_packet_ber"] = {"median": float(np.median(per) / cfg.bits_per_frame), "max": float(per.max() / cfg.bits_per_frame),
+                         "packets_above_5pct": int((per > 0.05 * cfg.bits_per_frame).sum())}
+same = True
+for f in worst:
+    s0 = int(starts[f].item())
+    seg2 = r[s0 - 100: s0 + cfg.M * cfg.S + 100].cpu().numpy().astype(np.float64)
+    ref2 = orc.demod_frames(seg2, np.array([100]), p)["bits"]
+    got2 = np.unpackbits(out[f].cpu().numpy())[: cfg.bits_per_frame]
+    same = same and bool(np.array_equal(ref2, got2))
+res["worst_packets_identical_to_oracle"] = same
 # and the sync offsets: the measured channel delays the peak by one sample
 exp = 64 + np.arange(F) * cfg.frame_len + cfg.chirp_length + 1
 res["sync_offsets_as_expected_plus1"] = bool(np.array_equal(starts.cpu().numpy(), exp))
+if not res["sync_offsets_as_expected_plus1"]:
+    d = starts.cpu().numpy() - exp
+    bad = np.flatnonzero(d != 0)
+    res["sync_offset_errors"] = {"count": int(len(bad)), "first_bad_frames": bad[:8].tolist(), "deltas": d[bad[:8]].tolist()}
 print(json.dumps(res))
