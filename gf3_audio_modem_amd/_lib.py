@@ -63,6 +63,13 @@ def load():
         return _lib
     path = lib_path()
     if not os.path.exists(path):
+        # not built yet: compile it here if the ROCm toolchain is present (same gfx950 build as
+        # __graft_entry__.build()); otherwise fail loudly -- there is no other implementation to fall back to
+        import shutil
+        from . import build as _build
+        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+            _build.build_lib()
+    if not os.path.exists(path):
         raise ImportError(
             f"{path} is not built. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the receive path.")
