@@ -858,7 +858,8 @@ __global__ __launch_bounds__(NC / 8, 2) void tx_kernel(TxArgs a) {
 // ============================================================================
 // host side: context + C ABI
 // ============================================================================
-struct CorrPlan { int Q = 0, Lp = 0, W = 0; cplx* d_Hq = nullptr; };
+// a correlation plan has its own FFT size: the chirp search need not use the OFDM symbol's N
+struct CorrPlan { int NC = 0, Q = 0, Lp = 0, W = 0; cplx* d_Hq = nullptr; FftTables t{nullptr, nullptr}; };
 
 struct gf3_ctx {
     gf3_config cfg;
@@ -866,6 +867,7 @@ struct gf3_ctx {
     int fit_lo, fit_hi;
     double xbar, inv_sxx;
     cplx *d_tw = nullptr, *d_twn = nullptr, *d_known = nullptr;
+    cplx *d_tw_h = nullptr, *d_twn_h = nullptr;       // tables for FFT size N/2 (frames-mode sync plan)
     int *d_pos = nullptr, *d_clab = nullptr;
     double *d_cre = nullptr, *d_cim = nullptr;
     CorrPlan frames_plan, stream_plan;
@@ -940,17 +942,28 @@ static hipError_t launch(Kern k, int64_t grid, int threads, size_t lds, hipStrea
     }
 #endif
 
+static hipError_t run_rfft_nc(int NCv, FftTables t, const void* d_in, int64_t n_in, int dt, const int64_t* d_off,
+                              int64_t n_sym, cplx* d_out, hipStream_t st) {
+    RfftArgs a{t, d_in, n_in, d_off, dt, d_out};
+    hipError_t e = hipSuccess;
+#ifdef GF3_DEV_BUILD
+    if (NCv == 1024) {
+        if (dt == DT_F64) return launch((rfft_kernel<1024, DT_F64>), n_sym, 128, fft_lds_bytes(1024), st, a);
+        return launch((rfft_kernel<1024, DT_F32>), n_sym, 128, fft_lds_bytes(1024), st, a);
+    }
+#endif
+    DISPATCH_NC(NCv, dt, e = launch((rfft_kernel<NCC, DTC>), n_sym, NCC / 8, fft_lds_bytes(NCC), st, a));
+    return e;
+}
 static hipError_t run_rfft(const gf3_ctx* c, const void* d_in, int64_t n_in, int dt, const int64_t* d_off,
                            int64_t n_sym, cplx* d_out, hipStream_t st) {
-    RfftArgs a{{c->d_tw, c->d_twn}, d_in, n_in, d_off, dt, d_out};
-    hipError_t e = hipSuccess;
-    DISPATCH_NC(c->NC, dt, e = launch((rfft_kernel<NCC, DTC>), n_sym, NCC / 8, fft_lds_bytes(NCC), st, a));
-    return e;
+    return run_rfft_nc(c->NC, FftTables{c->d_tw, c->d_twn}, d_in, n_in, dt, d_off, n_sym, d_out, st);
 }
 
 // spectra of the zero-padded chirp partitions, computed with the engine's own FFT
-static int build_plan(gf3_ctx* c, CorrPlan* pl, int Lp_max) {
-    const int N = 2 * c->NC;
+static int build_plan(gf3_ctx* c, CorrPlan* pl, int NCp, FftTables t, int Lp_max) {
+    const int N = 2 * NCp;
+    pl->NC = NCp; pl->t = t;
     int Q = (c->Lc + Lp_max - 1) / Lp_max;
     int Lp = (c->Lc + Q - 1) / Q;
     pl->Q = Q; pl->Lp = Lp; pl->W = N - Lp + 1;
@@ -962,8 +975,8 @@ static int build_plan(gf3_ctx* c, CorrPlan* pl, int Lp_max) {
     double* d_h = nullptr; int64_t* d_off = nullptr;
     HIPCHK(c, upload(&d_h, h.data(), h.size()));
     HIPCHK(c, upload(&d_off, off.data(), off.size()));
-    HIPCHK(c, hipMalloc((void**)&pl->d_Hq, (size_t)Q * (c->NC + 1) * sizeof(cplx)));
-    HIPCHK(c, run_rfft(c, d_h, (int64_t)h.size(), DT_F64, d_off, Q, pl->d_Hq, 0));
+    HIPCHK(c, hipMalloc((void**)&pl->d_Hq, (size_t)Q * (NCp + 1) * sizeof(cplx)));
+    HIPCHK(c, run_rfft_nc(NCp, t, d_h, (int64_t)h.size(), DT_F64, d_off, Q, pl->d_Hq, 0));
     HIPCHK(c, hipStreamSynchronize(0));
     (void)hipFree(d_h); (void)hipFree(d_off);
     return GF3_OK;
@@ -1103,8 +1116,24 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     c->cfg.const_bits = nullptr; c->cfg.data_bins = nullptr;
     int wmax = cfg->max_window > 0 ? cfg->max_window : 512;
     if (wmax > N / 2) wmax = N / 2;
-    int rc = build_plan(c, &c->frames_plan, N - wmax + 1);
-    if (rc == GF3_OK) rc = build_plan(c, &c->stream_plan, N / 2);
+    // frames-mode plan: (Q+1) transforms of size Nf per packet; pick Nf in {N, N/2} by cost ~ (Q+1) Nf log2 Nf
+    int NCf = NC;
+    if (NC >= 1024 && wmax <= NC / 2) {
+        auto cost = [&](int nc) { const int nf = 2 * nc, lp = nf - wmax + 1; const int q = (c->Lc + lp - 1) / lp;
+                                  return (double)(q + 1) * nf * log2((double)nf); };
+        if (cost(NC / 2) < cost(NC)) NCf = NC / 2;
+    }
+    FftTables tf{c->d_tw, c->d_twn};
+    if (NCf != NC) {
+        std::vector<cplx> twh(NCf), twnh(NCf / 2 + 1);
+        for (int m = 0; m < NCf; ++m) { const long double a2 = -PI2 * m / NCf; twh[m] = make_double2((double)cosl(a2), (double)sinl(a2)); }
+        for (int k = 0; k <= NCf / 2; ++k) { const long double a2 = -PI2 * k / (2 * NCf); twnh[k] = make_double2((double)cosl(a2), (double)sinl(a2)); }
+        hipError_t e1 = upload(&c->d_tw_h, twh.data(), twh.size()), e2 = upload(&c->d_twn_h, twnh.data(), twnh.size());
+        if (e1 != hipSuccess || e2 != hipSuccess) { gf3_ctx_destroy(c); return fail(nullptr, GF3_EHIP, "table upload failed"); }
+        tf = FftTables{c->d_tw_h, c->d_twn_h};
+    }
+    int rc = build_plan(c, &c->frames_plan, NCf, tf, 2 * NCf - wmax + 1);
+    if (rc == GF3_OK) rc = build_plan(c, &c->stream_plan, NC, FftTables{c->d_tw, c->d_twn}, N / 2);
     if (rc != GF3_OK) { memcpy(g_err, c->err, 512); gf3_ctx_destroy(c); return rc; }
     *out = c;
     return GF3_OK;
@@ -1112,7 +1141,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
 
 extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
     if (!c) return;
-    void* ptrs[] = {c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
+    void* ptrs[] = {c->d_tw_h, c->d_twn_h, c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
                     c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_known_time};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete c;
@@ -1251,10 +1280,17 @@ extern "C" int gf3_tx_frames(gf3_ctx* c, const uint8_t* d_bits_packed, const voi
     return tx_launch(c, a, F, st);
 }
 
-static hipError_t run_corr(const gf3_ctx* c, const CorrArgs& a, int64_t grid, hipStream_t st) {
-    const size_t lds = (GF3_CORR_PP ? fft_lds_bytes(c->NC) : (size_t)(c->NC + c->NC / 8) * sizeof(cplx)) + 32 * sizeof(double);
+static hipError_t run_corr(const gf3_ctx* c, const CorrPlan& pl, const CorrArgs& a, int64_t grid, hipStream_t st) {
+    const int NCp = pl.NC;
+    const size_t lds = (GF3_CORR_PP ? fft_lds_bytes(NCp) : (size_t)(NCp + NCp / 8) * sizeof(cplx)) + 32 * sizeof(double);
     hipError_t e = hipSuccess;
-    DISPATCH_NC(c->NC, a.dt, e = launch((corr_kernel<NCC, DTC>), grid, NCC / 8, lds, st, a));
+#ifdef GF3_DEV_BUILD
+    if (NCp == 1024) {
+        if (a.dt == DT_F64) return launch((corr_kernel<1024, DT_F64>), grid, 128, lds, st, a);
+        return launch((corr_kernel<1024, DT_F32>), grid, 128, lds, st, a);
+    }
+#endif
+    DISPATCH_NC(NCp, a.dt, e = launch((corr_kernel<NCC, DTC>), grid, NCC / 8, lds, st, a));
     return e;
 }
 
@@ -1266,10 +1302,10 @@ extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64
     const CorrPlan& pl = c->frames_plan;
     if (W < 3 || W > pl.W) return fail(c, GF3_EINVAL, "gf3_sync_frames: window %d outside [3, %d]", W, pl.W);
     CorrArgs a{};
-    a.t = {c->d_tw, c->d_twn}; a.in = d_in; a.n_in = n_in; a.dt = c->cfg.in_dtype;
+    a.t = pl.t; a.in = d_in; a.n_in = n_in; a.dt = c->cfg.in_dtype;
     a.Hq = pl.d_Hq; a.Q = pl.Q; a.Lp = pl.Lp; a.Lc = c->Lc; a.Wmax = W;
     a.stride = stride; a.win_lo = win_lo; a.W = W; a.starts = d_starts; a.peak = d_peak; a.thresh = c->cfg.thresh;
-    HIPCHK(c, run_corr(c, a, F, (hipStream_t)stream));
+    HIPCHK(c, run_corr(c, pl, a, F, (hipStream_t)stream));
     return GF3_OK;
 }
 
@@ -1314,11 +1350,11 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     int64_t* np = (int64_t*)(base + w.o_misc + 16);        // [count, status]
     const CorrPlan& pl = c->stream_plan;
     CorrArgs a{};
-    a.t = {c->d_tw, c->d_twn}; a.in = d_r; a.n_in = n; a.dt = c->cfg.in_dtype;
+    a.t = pl.t; a.in = d_r; a.n_in = n; a.dt = c->cfg.in_dtype;
     a.Hq = pl.d_Hq; a.Q = pl.Q; a.Lp = pl.Lp; a.Lc = c->Lc; a.Wmax = pl.W;
     a.starts = nullptr; a.V = pl.W; a.plen = w.plen; a.corr = P;
     const int64_t nblk = (w.plen + pl.W - 1) / pl.W;
-    HIPCHK(c, run_corr(c, a, nblk, st));
+    HIPCHK(c, run_corr(c, pl, a, nblk, st));
     hipLaunchKernelGGL(pk_max_partial, dim3((unsigned)w.nb_max), dim3(256), 0, st, (const double*)P, w.plen, part);
     hipLaunchKernelGGL(pk_max_final, dim3(1), dim3(256), 0, st, (const double*)part, (int)w.nb_max, mx);
     hipLaunchKernelGGL(pk_candidates, dim3((unsigned)w.nb_c), dim3(PK_THREADS), 0, st, (const double*)P, w.nz,
