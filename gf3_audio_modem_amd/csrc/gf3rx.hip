@@ -138,10 +138,18 @@ GF3_DEV uint32_t qpsk_scan(cplx e, double q) {
 // positive multiple of e): the scan's first-minimum rule breaks the four axis ties as
 // Re=0 -> Re>=0 side, Im=0 -> (Re<0 ? Im<0 side : Im>=0 side); NaN/Inf -> first point.
 GF3_DEV uint32_t qpsk_sign_rule(cplx e) {
-    const bool fin = (fabs(e.x) < INFINITY) && (fabs(e.y) < INFINITY);
-    const uint32_t b1 = e.x < 0.0 ? 1u : 0u;
-    const uint32_t b0 = (e.y < 0.0 || (e.y == 0.0 && e.x < 0.0)) ? 2u : 0u;
-    return fin ? (b0 | b1) : 0u;
+    // common case: both components are non-zero finite numbers -> the label is the two sign bits
+    const uint32_t hx = (uint32_t)__double2hiint(e.x), hy = (uint32_t)__double2hiint(e.y);
+    uint32_t lab = ((hy >> 31) << 1) | (hx >> 31);
+    // v_cmp_class: NaN (0x3), -inf (0x4), -0 (0x20), +0 (0x40), +inf (0x200)
+    const bool odd = __builtin_amdgcn_class(e.x, 0x267) || __builtin_amdgcn_class(e.y, 0x267);
+    if (odd) {
+        const bool fin = (fabs(e.x) < INFINITY) && (fabs(e.y) < INFINITY);
+        const uint32_t b1 = e.x < 0.0 ? 1u : 0u;
+        const uint32_t b0 = (e.y < 0.0 || (e.y == 0.0 && e.x < 0.0)) ? 2u : 0u;
+        lab = fin ? (b0 | b1) : 0u;
+    }
+    return lab;
 }
 
 // Nearest level on one axis with the margin to the runner-up; first minimum wins like argmin.
@@ -257,6 +265,9 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     };
     GF3_STAMP(0);
     if constexpr (!SPECTRA) fetch(0);
+    cplx ik[8];                                       // 1/known for this thread's carriers, needed after the pilots;
+#pragma unroll                                        // loaded now so the L2 latency hides under the pilot transforms
+    for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
 
     // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451)
     cplx Hs[8], He[8];
@@ -290,9 +301,6 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     cplx u[8];
     double a0[8], da[8], p0[8], p1[8];
     const double invP = 1.0 / (double)P;
-    cplx ik[8];                                       // 1/known for this thread's carriers
-#pragma unroll
-    for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int bn = bin_of(s);
