@@ -200,6 +200,13 @@ class receiver(transmitter):
         zeros[peaks] = True
         return zeros
 
+    # ---- alternative sync of the "standard" (OFDM.py:376-387; receive() never calls it) -------------
+    def schmidlcox_method(self, r):
+        r = _as_samples(r)
+        if len(r) < 5 * self.fs - 1 + 2 * self.L:
+            raise IndexError("index out of bounds: the stream is shorter than the 5 s search range")
+        return self._engine(r.dtype).schmidl_cox(r, 5 * self.fs)
+
     # ---- get_symbols / remove_cp / get_data: array plumbing (OFDM.py:391-418) ----
     def get_symbols(self, r, zeros):
         zero_indicies = np.where(zeros == True)[0] + 2        # noqa: E712  (OFDM.py:393)

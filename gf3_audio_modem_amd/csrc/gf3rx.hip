@@ -1287,6 +1287,83 @@ extern "C" int gf3_tx_frames(gf3_ctx* c, const uint8_t* d_bits_packed, const voi
     a.out = d_out; a.stride = stride; a.out_dt = out_dtype == GF3_F32 ? DT_F32 : DT_F64;
     return tx_launch(c, a, F, st);
 }
+// ============================================================================
+// Schmidl & Cox timing metric (receiver.schmidlcox_method, OFDM.py:376-387)
+//   P[0] = 0, P[d+1] = P[d] + r[d+L] r[d+2L] - r[d] r[d+L]; answer = first argmax |P| + N - 1
+// One workgroup walks the search range in chunks: per-thread terms -> wave shuffle scan -> carry;
+// the running arg-max keeps (|P|, smallest index) and is reduced across the block at the end.
+// ============================================================================
+struct ScArgs { const void* in; int dt; int64_t S; int L; int N; int64_t* out; };
+
+__global__ __launch_bounds__(1024) void schmidl_cox_kernel(ScArgs a) {
+    __shared__ double wsum[16];
+    __shared__ double bval[16];
+    __shared__ long long bidx[16];
+    __shared__ double carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int ITEMS = 4;
+    double best = 0.0;                 // |P[0]| = 0 at index 0
+    long long besti = 0;
+    double carry = 0.0;
+    for (int64_t base = 0; base < a.S - 1; base += 1024 * ITEMS) {
+        const int64_t d0 = base + (int64_t)tid * ITEMS;
+        double t[ITEMS], run = 0.0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int64_t d = d0 + k;
+            double x = 0.0;
+            if (d < a.S - 1) {
+                const double r0 = load_sample(a.in, d, a.dt), r1 = load_sample(a.in, d + a.L, a.dt),
+                             r2 = load_sample(a.in, d + 2 * a.L, a.dt);
+                x = r1 * r2 - r0 * r1;
+            }
+            run += x;
+            t[k] = run;                // inclusive prefix inside the thread
+        }
+        double incl = run;             // block-wide inclusive scan of the per-thread totals
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const double y = __shfl_up(incl, o, 64); if (lane >= o) incl += y; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        double woff = 0.0, tot = 0.0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+        const double before = carry + woff + (incl - run);
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int64_t d = d0 + k;
+            if (d < a.S - 1) {
+                const double v = fabs(before + t[k]);      // |P[d+1]|
+                if (v > best) { best = v; besti = d + 1; }
+            }
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    // arg-max with first-index tie rule: wave reduction, then across waves
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const double ov = __shfl_xor(best, o, 64);
+        const long long oi = __shfl_xor(besti, o, 64);
+        if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+    }
+    if (lane == 0) { bval[wave] = best; bidx[wave] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bval[w] > best || (bval[w] == best && bidx[w] < besti)) { best = bval[w]; besti = bidx[w]; }
+        a.out[0] = besti + a.N - 1;
+    }
+}
+
+extern "C" int gf3_schmidl_cox(gf3_ctx* c, const void* d_r, int64_t n, int64_t search_len, int64_t* d_index, void* stream) {
+    if (!c || !d_r || !d_index || search_len < 2) return fail(c, GF3_EINVAL, "gf3_schmidl_cox: bad argument");
+    const int L = c->K + 1;
+    if (n < search_len - 1 + 2 * (int64_t)L) return fail(c, GF3_EINVAL, "gf3_schmidl_cox: stream shorter than search length + 2L");
+    ScArgs a{d_r, c->cfg.in_dtype, search_len, L, 2 * c->NC, d_index};
+    hipLaunchKernelGGL(schmidl_cox_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+    HIPCHK(c, hipGetLastError());
+    return GF3_OK;
+}
 
 static hipError_t run_corr(const gf3_ctx* c, const CorrPlan& pl, const CorrArgs& a, int64_t grid, hipStream_t st) {
     const int NCp = pl.NC;

@@ -279,6 +279,14 @@ class Engine:
                                            _DT_OF[out_dtype], self._stream()))
         return out
 
+    def schmidl_cox(self, x, search_length=None):
+        """receiver.schmidlcox_method (OFDM.py:376-387): first arg-max of |P| + N - 1, as a Python int."""
+        x = self._samples(x).reshape(-1)
+        S = int(5 * self.cfg.fs) if search_length is None else int(search_length)
+        out = self._new((1,), torch.int64)
+        self._check(self.lib.gf3_schmidl_cox(self._h, _ptr(x), x.numel(), S, _ptr(out), self._stream()))
+        return int(out.item())
+
     def demap_hard(self, sym):
         sym = torch.as_tensor(sym, dtype=torch.complex128).to(self.device).contiguous()
         n = sym.numel()

@@ -164,6 +164,14 @@ int gf3_sync_stream(gf3_ctx *ctx, const void *d_r, int64_t n,
                     void *d_work, double *d_corr_or_null, void *stream);
 
 /*
+ * receiver.schmidlcox_method (OFDM.py:376-387; unused by receive()): running-sum
+ * autocorrelation metric P[d+1] = P[d] + r[d+L] r[d+2L] - r[d] r[d+L] (L = K+1) over search_len lags;
+ * *d_index (device int64) = first index of max |P| + N - 1.  Needs n >= search_len - 1 + 2L samples.
+ */
+int gf3_schmidl_cox(gf3_ctx *ctx, const void *d_r, int64_t n, int64_t search_len,
+                    int64_t *d_index, void *stream);
+
+/*
  * demap (OFDM.py:484-500) standalone: hard decisions for n symbols.
  * d_bits_u8: [n*mu] one byte per bit (0/1); d_idx_u8 (optional): [n] index of
  * the chosen constellation point (hardDecision = constellation[idx]).

@@ -465,3 +465,26 @@ def receive_rows(rows, p: RxParams, win_lo, win_hi):
     out = demod_frames(rows.reshape(-1), st + np.arange(len(rows)) * stride, p)
     out["starts"] = st
     return out
+
+
+# --------------------------------------------------------------------------
+# Schmidl & Cox timing metric (receiver.schmidlcox_method, OFDM.py:376-387; unused by receive())
+# --------------------------------------------------------------------------
+
+def schmidl_cox(r, p: RxParams, search_length=None):
+    """P[0] = 0, P[d+1] = P[d] + conj(r[d+L]) r[d+2L] - conj(r[d]) r[d+L] for d < search_length-1, L = K+1
+    (:379-385); returns the first index of max |P| plus N-1 (:387).  The running sum is evaluated in the
+    reference's order ((P + a) - b) by a cumulative sum over the interleaved terms."""
+    r = np.asarray(r, dtype=np.float64)
+    L = p.K + 1
+    S = int(5 * p.fs) if search_length is None else int(search_length)
+    if len(r) < S - 1 + 2 * L:
+        raise IndexError("stream shorter than the search length + 2L")
+    d = np.arange(S - 1)
+    a = r[d + L] * r[d + 2 * L]
+    b = r[d] * r[d + L]
+    inter = np.empty(2 * (S - 1))
+    inter[0::2] = a
+    inter[1::2] = -b
+    P = np.concatenate([[0.0], np.cumsum(inter)[1::2]])
+    return int(np.flatnonzero(np.abs(P) == np.amax(np.abs(P)))[0] + p.N - 1)

@@ -279,10 +279,24 @@ def make_known_bits():
     print("known_bits.npz written:", len(bits), "bits")
 
 
+def make_schmidlcox(OFDM):
+    """Schmidl & Cox metric (OFDM.py:376-387, unused by receive()): noise with one repeated-half symbol."""
+    rs = np.random.RandomState(99)
+    n = 5 * 48000 + 2 * 2048 + 100
+    r = (0.05 * rs.randn(n)).astype(np.float32)
+    half = rs.randn(2048).astype(np.float32)
+    r[61234:61234 + 2048] += half
+    r[61234 + 2048:61234 + 4096] += half
+    rx = OFDM.receiver(mode="A1", encoding="None")
+    idx = int(rx.schmidlcox_method(r.astype(np.float64)))
+    print("g9_schmidlcox: index", idx)
+    np.savez_compressed(os.path.join(HERE, "g9_schmidlcox.npz"), r=r, index=idx)
+
+
 def main():
     OFDM = import_reference()
     make_known_bits()
-    which = set(sys.argv[1:]) or {"g1", "g1b", "g2", "g3", "g4", "g5", "g6", "g7", "g8"}
+    which = set(sys.argv[1:]) or {"g1", "g1b", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"}
     h = np.loadtxt(os.path.join(REF, "Handouts", "gr5channel.csv")).reshape(-1)
     if "g1" in which:
         make_loopback(OFDM, "g1_n1024_qpsk", 1024, 128, 2, 8, 2, 2, seed=1)
@@ -300,6 +314,8 @@ def main():
     if "g8" in which:
         make_loopback(OFDM, "g8_n4096_qpsk_gr5_drift", 4096, 512, 2, 4, 2, 2, seed=5, channel=h,
                       drift=(1.0e-5, 1.0e-4, 22))
+    if "g9" in which:
+        make_schmidlcox(OFDM)
     if "g4" in which:
         make_fft(OFDM)
     if "g5" in which:

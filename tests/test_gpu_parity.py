@@ -422,3 +422,15 @@ def test_abi_error_paths():
         eng.tx_frames(np.zeros((2, eng.bytes_per_frame), np.uint8), np.zeros(511, complex), stride=100)
     with pytest.raises(ValueError, match="shapes"):
         eng.equalise(np.zeros((1, 8, 10), complex), np.zeros((1, 2, 511), complex), np.zeros((1, 2, 511), complex))
+
+
+def test_schmidl_cox_metric():
+    """gf3_schmidl_cox == the reference's schmidlcox_method on the g9 fixture (f32 and f64 storage), via the facade too."""
+    from gf3_audio_modem_amd.OFDM import receiver
+    g = load("g9_schmidlcox")
+    r = g["r"]
+    rx = receiver(mode="A1", encoding="None")
+    assert rx.schmidlcox_method(r) == int(g["index"])                       # float32 samples
+    assert rx.schmidlcox_method(r.astype(np.float64)) == int(g["index"])
+    with pytest.raises(IndexError):
+        rx.schmidlcox_method(r[:5000])

@@ -143,3 +143,11 @@ def test_real_recording_known_answer():
     ber = np.sum(bits[: len(src)] != src) / len(src)
     assert repr(float(ber)) == str(g["ber_str"])
     np.testing.assert_allclose(out["Hs"][0], g["Hs0"], rtol=0, atol=1e-12 * np.abs(g["Hs0"]).max())
+
+
+def test_schmidl_cox_matches_reference():
+    g = load("g9_schmidlcox")
+    p = orc.RxParams(N=4096, CP=224)
+    assert orc.schmidl_cox(g["r"].astype(np.float64), p) == int(g["index"])
+    with pytest.raises(IndexError):
+        orc.schmidl_cox(g["r"][:1000].astype(np.float64), p)
