@@ -611,6 +611,135 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
 }
 
 // ============================================================================
+// stream-mode matched filter: uniformly partitioned overlap-save with a spectral delay line
+// (convolve(r, chirp[::-1]) over a whole stream, OFDM.py:357-358).
+//   hop H = Lp (partition length).  Window j = samples [jH - (Lc-1), +N) is transformed ONCE
+//   (spec_kernel); output block b = lags [bH, (b+1)H) of P is
+//       P_b = irfft( sum_q  X_{b+q} . conj(H_q) )        (ols_kernel)
+//   so the cost per H lags is one forward and one inverse transform plus Q spectrum MACs,
+//   instead of Q+1 transforms.
+// ============================================================================
+struct OlsArgs {
+    FftTables t;
+    const void* in; int64_t n_in; int dt;
+    const cplx* Hq; int Q, H, Lc;
+    cplx* spec;               // [NWIN][NC+1]
+    int64_t nwin, plen;
+    double* corr;
+};
+
+template <int NC, int DT>
+__global__ __launch_bounds__(NC / 8, 2) void spec_kernel(OlsArgs a) {
+    extern __shared__ double2 smem[];
+    constexpr int T = NC / 8;
+    typedef typename RawT<DT>::E E;
+    const int tid = threadIdx.x;
+    const int64_t j = blockIdx.x;
+    const int64_t seg = j * (int64_t)a.H - (a.Lc - 1);
+    FftTw<NC> ft;
+    ft.init(tid, a.t.tw);
+    const cplx wb = a.t.twn[tid];
+    cplx v[8];
+    const bool inside = seg >= 0 && seg + 2 * NC <= a.n_in;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int64_t i = seg + 2 * (int64_t)(tid + r * T);
+        RawPair<DT> raw;
+        if (inside) raw.load(a.in, i);
+        else {
+            raw.zero();
+            if (i >= 0 && i < a.n_in) raw.v.a = ((const E*)a.in)[i];
+            if (i + 1 >= 0 && i + 1 < a.n_in) raw.v.b = ((const E*)a.in)[i + 1];
+        }
+        v[r] = raw.get();
+    }
+    cplx z0;
+    rfft_regs<NC>(v, smem, ft, wb, tid, z0, 0);
+    cplx* out = a.spec + j * (int64_t)(NC + 1);
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2)
+        if (Spec<NC>::live(tid, s2)) out[Spec<NC>::bin(tid, s2)] = v[s2];
+    if (tid == 0) {
+        out[0] = cmk(z0.x + z0.y, 0.0);
+        out[NC] = cmk(z0.x - z0.y, 0.0);
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
+    // Two adjacent output blocks per workgroup: blocks b and b+1 need windows b..b+Q and share Q-1 of
+    // them, so every window spectrum is fetched once for two MACs (the kernel is bound by those reads).
+    extern __shared__ double2 smem[];
+    constexpr int T = NC / 8;
+    cplx* lds = smem;
+    const int tid = threadIdx.x;
+    const int64_t b = 2 * (int64_t)blockIdx.x;
+    FftTw<NC> ft;
+    ft.init(tid, a.t.tw);
+    cplx wb = a.t.twn[tid];
+    cplx acc0[8], acc1[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc0[s] = acc1[s] = cmk(0.0, 0.0);
+    double dc0 = 0.0, ny0 = 0.0, dc1 = 0.0, ny1 = 0.0;
+    for (int q = 0; q <= a.Q; ++q) {                 // window b+q feeds block b with H_q and block b+1 with H_{q-1}
+        const cplx* X = a.spec + (b + q) * (int64_t)(NC + 1);
+        const cplx* H0 = a.Hq + (int64_t)(q < a.Q ? q : 0) * (NC + 1);
+        const cplx* H1 = a.Hq + (int64_t)(q > 0 ? q - 1 : 0) * (NC + 1);
+        const bool use0 = q < a.Q, use1 = q > 0 && (b + q) < a.nwin;
+        if (!(b + q < a.nwin)) break;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = Spec<NC>::bin(tid, s);
+            const cplx x = X[k];
+            if (use0) acc0[s] = cadd(acc0[s], cmul_conj(x, H0[k]));
+            if (use1) acc1[s] = cadd(acc1[s], cmul_conj(x, H1[k]));
+        }
+        if (tid == 0) {
+            const double x0 = X[0].x, xn = X[NC].x;
+            if (use0) { dc0 += x0 * H0[0].x; ny0 += xn * H0[NC].x; }
+            if (use1) { dc1 += x0 * H1[0].x; ny1 += xn * H1[NC].x; }
+        }
+    }
+    const double inv = 1.0 / (double)NC;
+    for (int g = 0; g < 2; ++g) {
+        const int64_t m0 = (b + g) * (int64_t)a.H;
+        if (m0 >= a.plen) break;
+        lds_barrier();                                // previous output fully read out of LDS
+        // inverse real FFT of the Hermitian spectrum (same construction as corr_kernel)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = Spec<NC>::bin(tid, 2 * r);
+            const cplx A = g ? acc1[2 * r] : acc0[2 * r];
+            const cplx B = cconj(g ? acc1[2 * r + 1] : acc0[2 * r + 1]);
+            const cplx E = cscale(cadd(A, B), 0.5);
+            const cplx Op = cmul_conj(cscale(csub(A, B), 0.5), Spec<NC>::pair_tw(tid, r, wb));
+            const cplx Zk = cadd(E, mul_posi(Op));
+            const cplx Zm = cadd(cconj(E), mul_posi(cconj(Op)));
+            lds[k] = cconj(Zk);
+            if (Spec<NC>::live(tid, 2 * r + 1)) lds[NC - k] = cconj(Zm);
+        }
+        if (tid == 0) {
+            const double dc = g ? dc1 : dc0, ny = g ? ny1 : ny0;
+            lds[0] = cmk(0.5 * (dc + ny), -0.5 * (dc - ny));
+        }
+        lds_barrier();
+        cplx v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = lds[tid + r * T];
+        lds_barrier();
+        ft.refresh();
+        cplx* yb = fft_core<NC>(v, lds, ft, tid);
+        const int64_t left = a.plen - m0;
+        const int W = left < a.H ? (int)left : a.H;
+        for (int i = tid; 2 * i < W; i += T) {        // y[2n] = Re z / NC, y[2n+1] = -Im z / NC
+            const cplx z = yb[i];
+            a.corr[m0 + 2 * i] = z.x * inv;
+            if (2 * i + 1 < W) a.corr[m0 + 2 * i + 1] = -z.y * inv;
+        }
+    }
+}
+
+// ============================================================================
 // stream-mode peak picking on the full correlation P (OFDM.py:359-370)
 // ============================================================================
 #define PK_THREADS 256
@@ -681,25 +810,34 @@ __global__ void pk_scan(const int64_t* counts, int64_t n, int64_t* offsets, int6
     }
     if (threadIdx.x == 0) total[0] = carry;
 }
-// sequential suppression (OFDM.py:364-370) over the sorted candidate list
+// sequential suppression (OFDM.py:364-370) over the sorted candidate list, one wave:
+// an accepted candidate i suppresses everything up to i+Lc, so the next survivor is the first
+// candidate >= i+Lc+1; the wave probes 64 list entries per step and ballots for the first hit
+// (the next chirp's cluster is normally within a few entries), falling back to larger strides.
 __global__ void pk_nms(const int64_t* cand, const int64_t* totalp, int64_t Lc, int64_t nz,
                        int64_t* peaks, int64_t cap, int64_t* npeaks) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
     const int64_t total = totalp[0];
-    int64_t pos = 0, np = 0;
-    int64_t status = 0;
+    int64_t pos = 0, np = 0, status = 0;
     while (pos < total) {
-        const int64_t i = cand[pos];
-        if (i + Lc >= nz) { np = 0; status = 1; break; }          // the except-branch wipes everything
-        if (np < cap) peaks[np] = i; else status = 2;
+        const int64_t i = cand[pos];                                 // wave-uniform
+        if (i + Lc >= nz) { np = 0; status = 1; break; }             // the except-branch wipes everything
+        if (lane == 0) { if (np < cap) peaks[np] = i; }
+        if (np >= cap) status = 2;
         ++np;
-        const int64_t want = i + Lc + 1;                            // first candidate past the cleared run
-        int64_t lo = pos + 1, hi = total;
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cand[mid] < want) lo = mid + 1; else hi = mid; }
+        const int64_t want = i + Lc + 1;
+        int64_t lo = pos + 1;
+        for (;;) {                                                   // first index >= lo with cand >= want
+            const int64_t k = lo + lane;
+            const bool hit = (k >= total) || (cand[k] >= want);
+            const unsigned long long m = __ballot(hit);
+            if (m) { lo += __builtin_ctzll(m); break; }
+            lo += 64;
+        }
         pos = lo;
     }
-    npeaks[0] = np;
-    npeaks[1] = status;
+    if (lane == 0) { npeaks[0] = np; npeaks[1] = status; }
 }
 
 // ============================================================================
@@ -1395,7 +1533,7 @@ extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64
 }
 
 // workspace layout for gf3_sync_stream
-struct StreamWs { int64_t plen, nz, nb_max, nb_c; size_t o_P, o_part, o_cnt, o_off, o_cand, o_misc, total; };
+struct StreamWs { int64_t plen, nz, nb_max, nb_c, nblk, nwin; size_t o_P, o_part, o_cnt, o_off, o_cand, o_misc, o_spec, total; };
 static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
     StreamWs w;
     w.plen = n + c->Lc - 1; w.nz = w.plen - 2;
@@ -1410,6 +1548,9 @@ static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
     w.o_off = take((size_t)w.nb_c * 8);
     w.o_cand = take((size_t)(w.nz / 2 + 2) * 8);
     w.o_misc = take(64);
+    w.nblk = (w.plen + c->stream_plan.Lp - 1) / c->stream_plan.Lp;
+    w.nwin = w.nblk + c->stream_plan.Q - 1;
+    w.o_spec = take((size_t)w.nwin * (c->stream_plan.NC + 1) * sizeof(cplx));
     w.total = o;
     return w;
 }
@@ -1434,12 +1575,25 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     int64_t* total = (int64_t*)(base + w.o_misc + 8);
     int64_t* np = (int64_t*)(base + w.o_misc + 16);        // [count, status]
     const CorrPlan& pl = c->stream_plan;
-    CorrArgs a{};
-    a.t = pl.t; a.in = d_r; a.n_in = n; a.dt = c->cfg.in_dtype;
-    a.Hq = pl.d_Hq; a.Q = pl.Q; a.Lp = pl.Lp; a.Lc = c->Lc; a.Wmax = pl.W;
-    a.starts = nullptr; a.V = pl.W; a.plen = w.plen; a.corr = P;
-    const int64_t nblk = (w.plen + pl.W - 1) / pl.W;
-    HIPCHK(c, run_corr(c, pl, a, nblk, st));
+    {
+        OlsArgs a{};
+        a.t = pl.t; a.in = d_r; a.n_in = n; a.dt = c->cfg.in_dtype;
+        a.Hq = pl.d_Hq; a.Q = pl.Q; a.H = pl.Lp; a.Lc = c->Lc;
+        a.spec = (cplx*)(base + w.o_spec); a.nwin = w.nwin; a.plen = w.plen; a.corr = P;
+        const size_t lds = fft_lds_bytes(pl.NC);
+        hipError_t e = hipSuccess;
+        DISPATCH_NC(pl.NC, a.dt, e = launch((spec_kernel<NCC, DTC>), w.nwin, NCC / 8, lds, st, a));
+        HIPCHK(c, e);
+        switch (pl.NC) {
+#ifndef GF3_DEV_BUILD
+            case 512:  e = launch(ols_kernel<512>, (w.nblk + 1) / 2, 64, lds, st, a); break;
+            case 1024: e = launch(ols_kernel<1024>, (w.nblk + 1) / 2, 128, lds, st, a); break;
+            case 4096: e = launch(ols_kernel<4096>, (w.nblk + 1) / 2, 512, lds, st, a); break;
+#endif
+            default:   e = launch(ols_kernel<2048>, (w.nblk + 1) / 2, 256, lds, st, a); break;
+        }
+        HIPCHK(c, e);
+    }
     hipLaunchKernelGGL(pk_max_partial, dim3((unsigned)w.nb_max), dim3(256), 0, st, (const double*)P, w.plen, part);
     hipLaunchKernelGGL(pk_max_final, dim3(1), dim3(256), 0, st, (const double*)part, (int)w.nb_max, mx);
     hipLaunchKernelGGL(pk_candidates, dim3((unsigned)w.nb_c), dim3(PK_THREADS), 0, st, (const double*)P, w.nz,
