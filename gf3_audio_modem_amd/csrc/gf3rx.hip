@@ -1013,7 +1013,8 @@ struct gf3_ctx {
     int fit_lo, fit_hi;
     double xbar, inv_sxx;
     cplx *d_tw = nullptr, *d_twn = nullptr, *d_known = nullptr;
-    cplx *d_tw_h = nullptr, *d_twn_h = nullptr;       // tables for FFT size N/2 (frames-mode sync plan)
+    cplx *d_tw_x[2] = {nullptr, nullptr}, *d_twn_x[2] = {nullptr, nullptr};   // twiddles of plans whose FFT size != N
+    int nc_x[2] = {0, 0};
     int *d_pos = nullptr, *d_clab = nullptr;
     double *d_cre = nullptr, *d_cim = nullptr;
     CorrPlan frames_plan, stream_plan;
@@ -1269,17 +1270,29 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
                                   return (double)(q + 1) * nf * log2((double)nf); };
         if (cost(NC / 2) < cost(NC)) NCf = NC / 2;
     }
-    FftTables tf{c->d_tw, c->d_twn};
-    if (NCf != NC) {
-        std::vector<cplx> twh(NCf), twnh(NCf / 2 + 1);
-        for (int m = 0; m < NCf; ++m) { const long double a2 = -PI2 * m / NCf; twh[m] = make_double2((double)cosl(a2), (double)sinl(a2)); }
-        for (int k = 0; k <= NCf / 2; ++k) { const long double a2 = -PI2 * k / (2 * NCf); twnh[k] = make_double2((double)cosl(a2), (double)sinl(a2)); }
-        hipError_t e1 = upload(&c->d_tw_h, twh.data(), twh.size()), e2 = upload(&c->d_twn_h, twnh.data(), twnh.size());
-        if (e1 != hipSuccess || e2 != hipSuccess) { gf3_ctx_destroy(c); return fail(nullptr, GF3_EHIP, "table upload failed"); }
-        tf = FftTables{c->d_tw_h, c->d_twn_h};
-    }
+    auto tables_for = [&](int NCp, FftTables& t) -> bool {         // twiddle set for a plan's FFT size
+        if (NCp == NC) { t = FftTables{c->d_tw, c->d_twn}; return true; }
+        for (int i = 0; i < 2; ++i) if (c->nc_x[i] == NCp) { t = FftTables{c->d_tw_x[i], c->d_twn_x[i]}; return true; }
+        const int i = c->nc_x[0] ? 1 : 0;
+        std::vector<cplx> twh(NCp), twnh(NCp / 2 + 1);
+        for (int m = 0; m < NCp; ++m) { const long double a2 = -PI2 * m / NCp; twh[m] = make_double2((double)cosl(a2), (double)sinl(a2)); }
+        for (int k = 0; k <= NCp / 2; ++k) { const long double a2 = -PI2 * k / (2 * NCp); twnh[k] = make_double2((double)cosl(a2), (double)sinl(a2)); }
+        if (upload(&c->d_tw_x[i], twh.data(), twh.size()) != hipSuccess) return false;
+        if (upload(&c->d_twn_x[i], twnh.data(), twnh.size()) != hipSuccess) return false;
+        c->nc_x[i] = NCp;
+        t = FftTables{c->d_tw_x[i], c->d_twn_x[i]};
+        return true;
+    };
+    // stream-mode plan (spectral delay line, hop = partition length): FFT size 2N where the kernels exist --
+    // half as many partitions, half the spectrum bytes per lag
+    int NCs = NC;
+#ifndef GF3_DEV_BUILD
+    if (2 * NC <= 4096) NCs = 2 * NC;
+#endif
+    FftTables tf, ts;
+    if (!tables_for(NCf, tf) || !tables_for(NCs, ts)) { gf3_ctx_destroy(c); return fail(nullptr, GF3_EHIP, "table upload failed"); }
     int rc = build_plan(c, &c->frames_plan, NCf, tf, 2 * NCf - wmax + 1);
-    if (rc == GF3_OK) rc = build_plan(c, &c->stream_plan, NC, FftTables{c->d_tw, c->d_twn}, N / 2);
+    if (rc == GF3_OK) rc = build_plan(c, &c->stream_plan, NCs, ts, NCs);
     if (rc != GF3_OK) { memcpy(g_err, c->err, 512); gf3_ctx_destroy(c); return rc; }
     *out = c;
     return GF3_OK;
@@ -1287,7 +1300,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
 
 extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
     if (!c) return;
-    void* ptrs[] = {c->d_tw_h, c->d_twn_h, c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
+    void* ptrs[] = {c->d_tw_x[0], c->d_twn_x[0], c->d_tw_x[1], c->d_twn_x[1], c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
                     c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_known_time};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete c;
