@@ -73,11 +73,8 @@ struct CorrArgs {
     const void* in; int64_t n_in; int dt;
     const cplx* Hq;           // [Q][NC+1] spectra of the zero-padded chirp partitions
     int Q, Lp, Lc, Wmax;
-    // frames mode
-    int64_t stride; int win_lo; int W;
+    int64_t stride; int win_lo; int W;      // window f = chirp-start lags [f*stride + win_lo, +W)
     int64_t* starts; double* peak; double thresh;
-    // stream mode (starts == nullptr): block b resolves P[b*V .. b*V+V)
-    int V; int64_t plen; double* corr;
 };
 
 // ============================================================================
@@ -472,8 +469,8 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 }
 
 // ============================================================================
-// chirp matched filter by partitioned FFT correlation
-// (convolve(r, chirp[::-1]) + peak rule, OFDM.py:357-361)
+// chirp matched filter by partitioned FFT correlation, one search window per workgroup
+// (convolve(r, chirp[::-1]) + peak rule, OFDM.py:357-361; whole streams: spec_kernel + ols_kernel)
 //   corr[s] = sum_k r[s+k] c[k],  s = s0 .. s0+W-1   (== P[s+Lc-1])
 //   c split into Q partitions of Lp taps; each partition's contribution is a
 //   circular correlation of size N = 2NC, valid for lags < N-Lp+1.
@@ -493,16 +490,8 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
     double* scratch = (double*)(smem + (PP ? FftGeom<NC>::LDS_ELEMS : FftGeom<NC>::LDS_ELEMS_INPLACE));
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x;
-    const bool frames = a.starts != nullptr;
-    int64_t s0;                  // absolute sample index of lag 0 of this block
-    int W;                       // lags this block must resolve
-    if (frames) { s0 = b * a.stride + a.win_lo; W = a.W; }
-    else {
-        const int64_t m0 = b * (int64_t)a.V;
-        s0 = m0 - (a.Lc - 1);
-        const int64_t left = a.plen - m0;
-        W = left < a.V ? (int)left : a.V;
-    }
+    const int64_t s0 = b * a.stride + a.win_lo;      // absolute sample index of lag 0 of this window
+    const int W = a.W;                               // lags to resolve
 
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
@@ -587,11 +576,6 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
     lds_barrier();
     const double* y = (const double*)yb;
 
-    if (!frames) {
-        const int64_t m0 = b * (int64_t)a.V;
-        for (int j = tid; j < W; j += T) a.corr[m0 + j] = y[j];
-        return;
-    }
     // ---- peak rule on the window (OFDM.py:359-361): normalise by the max, first
     // local extremum above thresh
     double mx = -INFINITY;
