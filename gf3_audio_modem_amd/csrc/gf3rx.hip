@@ -266,22 +266,41 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 #pragma unroll                                        // loaded now so the L2 latency hides under the pilot transforms
     for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
 
-    // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451)
+    // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451).
+    // The mean of the P pilot spectra is the spectrum of the mean pilot symbol (the DFT is linear), so
+    // the P symbols of a side are summed in the time domain, sample by sample as they arrive, and ONE
+    // transform per side replaces P (differs from the reference's order of additions by rounding only).
     cplx Hs[8], He[8];
+    if constexpr (SPECTRA) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) Hs[s] = He[s] = cmk(0.0, 0.0);
-    for (int i = 0; i < P; ++i) {
-        if (i == 1) GF3_STAMP(1);
-        if constexpr (SPECTRA) load_spectra(a.sp_start + ((int64_t)f * P + i) * K);
-        else transform(i);
+        for (int s = 0; s < 8; ++s) Hs[s] = He[s] = cmk(0.0, 0.0);
+        for (int i = 0; i < P; ++i) {
+            load_spectra(a.sp_start + ((int64_t)f * P + i) * K);
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) Hs[s2] = cadd(Hs[s2], v[s2]);
-    }
-    for (int i = P; i < 2 * P; ++i) {
-        if constexpr (SPECTRA) load_spectra(a.sp_end + ((int64_t)f * P + (i - P)) * K);
-        else transform(i);
+            for (int s2 = 0; s2 < 8; ++s2) Hs[s2] = cadd(Hs[s2], v[s2]);
+            load_spectra(a.sp_end + ((int64_t)f * P + i) * K);
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) He[s2] = cadd(He[s2], v[s2]);
+            for (int s2 = 0; s2 < 8; ++s2) He[s2] = cadd(He[s2], v[s2]);
+        }
+    } else {
+        for (int side = 0; side < 2; ++side) {
+            cplx sum[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) sum[r] = cmk(0.0, 0.0);
+            for (int i = side * P; i < (side + 1) * P; ++i) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) sum[r] = cadd(sum[r], nxt[r].get());
+                if (i + 1 < Msym) fetch(i + 1);                    // next pilot, or the first data symbol
+            }
+            if (side == 0) GF3_STAMP(1);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = sum[r];
+            ft.refresh();
+            asm volatile("" : "+v"(wb.x), "+v"(wb.y));
+            rfft_regs<NC, DemodOcc<NC, MODE>::PP>(v, lds, ft, wb, tq, z0, side);
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) { if (side) He[s2] = v[s2]; else Hs[s2] = v[s2]; }
+        }
     }
 
     // ---- per carrier: H = mean / known; equaliser state
