@@ -265,6 +265,8 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     cplx ik[8];                                       // 1/known for this thread's carriers, needed after the pilots;
 #pragma unroll                                        // loaded now so the L2 latency hides under the pilot transforms
     for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
+#pragma unroll                                        // pin them here: without a use the compiler sinks these loads
+    for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(ik[s].x), "v"(ik[s].y));   // to the finalize stage again
 
     // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451).
     // The mean of the P pilot spectra is the spectrum of the mean pilot symbol (the DFT is linear), so
@@ -317,29 +319,35 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     cplx u[8];
     double a0[8], da[8], p0[8], p1[8];
     const double invP = 1.0 / (double)P;
+    // (a) straight-line over the 8 slots (independent chains overlap): H = mean/known, unit phasor, magnitudes
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        Hs[s] = cmul(cscale(Hs[s], invP), ik[s]);
+        He[s] = cmul(cscale(He[s], invP), ik[s]);
+        const double m2 = Hs[s].x * Hs[s].x + Hs[s].y * Hs[s].y;
+        const double ia = rsq_nr(m2);                                 // 1/|Hs|
+        if constexpr (MODE != MODE_QPSK) {
+            const double e2 = He[s].x * He[s].x + He[s].y * He[s].y;
+            a0[s] = m2 * ia;                                          // |Hs|
+            da[s] = e2 * rsq_nr(e2) - a0[s];                          // |He| - |Hs|
+        }
+        u[s] = cmk(Hs[s].x * ia, Hs[s].y * ia);
+        p0[s] = 0.0; p1[s] = 0.0;
+    }
+    // (b) optional dumps and the angles of the carriers inside the fit range
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int bn = bin_of(s);
-        const cplx hs = cmul(cscale(Hs[s], invP), ik[s]);
-        const cplx he = cmul(cscale(He[s], invP), ik[s]);
-        p0[s] = 0.0; p1[s] = 0.0;
         if (live_of(s)) {
-            if (a.Hs) a.Hs[f * K + bn - 1] = hs;
-            if (a.He) a.He[f * K + bn - 1] = he;
+            if (a.Hs) a.Hs[f * K + bn - 1] = Hs[s];
+            if (a.He) a.He[f * K + bn - 1] = He[s];
             if (bn - 1 >= a.fit_lo && bn - 1 < a.fit_hi) {
-                p0[s] = atan2_fast(hs.y, hs.x);
-                p1[s] = atan2_fast(he.y, he.x);
+                p0[s] = atan2_fast(Hs[s].y, Hs[s].x);
+                p1[s] = atan2_fast(He[s].y, He[s].x);
                 ph0[bn - 1] = p0[s];
                 ph1[bn - 1] = p1[s];
             }
         }
-        const double ahs = sqrt(hs.x * hs.x + hs.y * hs.y);
-        if constexpr (MODE != MODE_QPSK) {
-            a0[s] = ahs;
-            da[s] = sqrt(he.x * he.x + he.y * he.y) - ahs;
-        }
-        const double ia = rcp_nr(ahs);
-        u[s] = cmk(hs.x * ia, hs.y * ia);
     }
     lds_barrier();
     double slope;

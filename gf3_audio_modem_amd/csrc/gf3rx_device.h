@@ -450,6 +450,13 @@ GF3_DEV double rcp_nr(double x) {
     e = fma(-x, y, 1.0);
     return fma(y, e, y);
 }
+// 1/sqrt(x): v_rsq_f64 seed + two Newton steps
+GF3_DEV double rsq_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    return y * fma(-hx * y, y, 1.5);
+}
 GF3_DEV cplx cis_fast(double x) { double s, c; sincos_fast(x, s, c); return cmk(c, s); }
 
 // atan2 with fdlibm's atan kernel (break points 7/16, 11/16; 11-term odd polynomial),

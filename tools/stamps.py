@@ -26,8 +26,14 @@ for _ in range(3):
 torch.cuda.synchronize()
 s = st.cpu().numpy().astype(np.float64)
 d = np.diff(s[:, :6], axis=1)
-names = ["start -> first pilot done", "remaining pilots", "finalize (H, angles, slope)", "data symbols", "last pack + exit"]
+names = ["start + start-pilot sum", "start + end pilot transforms", "finalize (H, angles, slope)", "data symbols", "last pack + exit"]
 tot = s[:, 5] - s[:, 0]
 print("median block lifetime (s_memtime ticks):", np.median(tot))
 for i, nme in enumerate(names):
     print(f"  {nme:32s} median {np.median(d[:, i]):10.0f}  share {np.median(d[:, i]) / np.median(tot):6.1%}")
+
+# finer stamps inside finalize when present (slots 6, 7 of a build that sets them)
+if s[:, 6].max() > 0:
+    print("  finalize: per-carrier H/angles   median", np.median(s[:, 6] - s[:, 2]))
+    print("  finalize: barrier + slope sums   median", np.median(s[:, 7] - s[:, 6]))
+    print("  finalize: rotation-table init    median", np.median(s[:, 3] - s[:, 7]))
