@@ -5,7 +5,7 @@ Layout
   _lib.py    ctypes binding of that ABI (fails loudly when the library is missing)
   engine.py  Engine: torch-tensor front end of the ABI (device memory + streams only)
   OFDM.py    drop-in mirror of the reference's `receiver` class (same names/shapes)
-  dist.py    frame sharding across GPUs + the single RCCL all-gather of packed bits
+  dist.py    frame sharding across GPUs + the all-gather of packed bits (overlapped per chunk)
 """
 from .engine import Engine, RxConfig, qpsk_table, square_qam_table  # noqa: F401
 

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, ctypes as C
 from gf3_audio_modem_amd import build
 if os.environ.get("GF3_LIB"): build.LIB = os.environ["GF3_LIB"]
-from gf3_audio_modem_amd import Engine, RxConfig, qpsk_table, synth
+from gf3_audio_modem_amd import Engine, RxConfig, qpsk_table
 
 N, CP, P, D, F = 4096, 512, 2, 8, 16384
 K = N // 2 - 1
@@ -16,9 +16,12 @@ cfg = RxConfig(N=N, CP=CP, P=P, D=D, data_bins=np.arange(1, K), const_points=pts
                in_dtype=torch.float32, max_window=320)
 eng = Engine(cfg)
 stride = 78720
-rows, payload, gaps = synth.make_frames(cfg, eng.chirp_replica(), 32, seed=1, stride=stride, dtype=torch.float32)
-big = synth.tile_rows(rows, F)
-starts = eng.sync_frames(big, F, stride, 0, 320)
+gen = torch.Generator(device="cuda").manual_seed(1)
+payload = torch.randint(0, 256, (F, eng.bytes_per_frame), dtype=torch.uint8, device="cuda", generator=gen)
+gaps = torch.randint(0, 300, (F,), dtype=torch.int64, device="cuda", generator=gen)
+filler = np.zeros(K, dtype=complex); filler[K - 1] = pts[0]
+big = eng.tx_frames(payload, filler, stride=stride, gaps=gaps, out_dtype=torch.float32)
+starts = eng.sync_frames(big, F, stride, -8, 312)
 st = torch.zeros((F, 8), dtype=torch.int64, device="cuda")
 eng.lib.gf3_debug_set_stamps(eng._h, C.c_void_p(st.data_ptr()))
 for _ in range(3):
