@@ -1032,7 +1032,7 @@ struct gf3_ctx {
     double qpsk_q = 0.0;
     int* d_idx_of_label = nullptr;
     double* d_chirp = nullptr;
-    double* d_known_time = nullptr;     // built on first use by gf3_tx_frames
+    double* d_known_time = nullptr;     // one pilot symbol in the time domain (transmit side)
     SepTab sep{};
     unsigned long long* stamps = nullptr;
     int contig_lo = 0;
@@ -1139,6 +1139,8 @@ static int build_plan(gf3_ctx* c, CorrPlan* pl, int NCp, FftTables t, int Lp_max
     (void)hipFree(d_h); (void)hipFree(d_off);
     return GF3_OK;
 }
+
+static int build_known_time(gf3_ctx* c);
 
 extern "C" const char* gf3_version(void) { return GF3RX_VERSION; }
 
@@ -1304,6 +1306,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     if (!tables_for(NCf, tf) || !tables_for(NCs, ts)) { gf3_ctx_destroy(c); return fail(nullptr, GF3_EHIP, "table upload failed"); }
     int rc = build_plan(c, &c->frames_plan, NCf, tf, 2 * NCf - wmax + 1);
     if (rc == GF3_OK) rc = build_plan(c, &c->stream_plan, NCs, ts, NCs);
+    if (rc == GF3_OK) rc = build_known_time(c);
     if (rc != GF3_OK) { memcpy(g_err, c->err, 512); gf3_ctx_destroy(c); return rc; }
     *out = c;
     return GF3_OK;
@@ -1409,6 +1412,37 @@ static int tx_launch(gf3_ctx* c, const TxArgs& a, int64_t F, hipStream_t st) {
     return GF3_OK;
 }
 
+// Known pilot symbol in the time domain (with prefix, before the x2 gain), built once at context
+// creation with the transmit kernel itself: a one-symbol packet whose "filler" is the known-symbol
+// vector and which has no data carriers.
+static int build_known_time(gf3_ctx* c) {
+    const gf3_config& g = c->cfg;
+    TxArgs a{};
+    a.t = {c->d_tw, c->d_twn};
+    a.CP = g.CP; a.S = c->S; a.K = c->K; a.mu = g.mu; a.M = g.M; a.Lc = c->Lc;
+    a.cre = c->d_cre; a.cim = c->d_cim; a.idx_of_label = c->d_idx_of_label; a.chirp = c->d_chirp;
+    cplx* d_kn = nullptr; double* d_row = nullptr; int* d_nopos = nullptr; uint8_t* d_nobits = nullptr;
+    std::vector<int> nopos(c->K, -1);
+    const int64_t rowlen = c->Lc + c->S;
+    HIPCHK(c, upload(&d_kn, c->known_pts.data(), c->known_pts.size()));
+    HIPCHK(c, upload(&d_nopos, nopos.data(), nopos.size()));
+    HIPCHK(c, hipMalloc((void**)&d_row, rowlen * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&d_nobits, 16));
+    HIPCHK(c, hipMalloc((void**)&c->d_known_time, c->S * sizeof(double)));
+    HIPCHK(c, hipMemset(c->d_known_time, 0, c->S * sizeof(double)));
+    a.P = 0; a.D = 1; a.C = 0; a.pos = d_nopos; a.contig_lo = 0; a.filler = d_kn; a.known_time = c->d_known_time;
+    a.bits = d_nobits; a.row_bytes = 0; a.gaps = nullptr; a.out = d_row; a.stride = rowlen; a.out_dt = DT_F64;
+    int rc = tx_launch(c, a, 1, 0);
+    if (rc != GF3_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(0));
+    std::vector<double> h(c->S);
+    HIPCHK(c, hipMemcpy(h.data(), d_row + c->Lc, c->S * sizeof(double), hipMemcpyDeviceToHost));
+    for (auto& x : h) x *= 0.5;                          // stored before the x2 gain
+    HIPCHK(c, hipMemcpy(c->d_known_time, h.data(), c->S * sizeof(double), hipMemcpyHostToDevice));
+    (void)hipFree(d_kn); (void)hipFree(d_row); (void)hipFree(d_nopos); (void)hipFree(d_nobits);
+    return GF3_OK;
+}
+
 extern "C" int gf3_tx_frames(gf3_ctx* c, const uint8_t* d_bits_packed, const void* d_filler_c128, const int64_t* d_gaps,
                              int64_t F, void* d_out, int64_t stride, int32_t out_dtype, void* stream) {
     if (c && F == 0) return GF3_OK;
@@ -1421,29 +1455,6 @@ extern "C" int gf3_tx_frames(gf3_ctx* c, const uint8_t* d_bits_packed, const voi
     a.t = {c->d_tw, c->d_twn};
     a.CP = g.CP; a.S = c->S; a.K = c->K; a.mu = g.mu; a.M = g.M; a.Lc = c->Lc;
     a.pos = c->d_pos; a.cre = c->d_cre; a.cim = c->d_cim; a.idx_of_label = c->d_idx_of_label; a.chirp = c->d_chirp;
-    if (!c->d_known_time) {
-        // one "data" symbol with zero data carriers: every bin takes the known symbol as its filler
-        cplx* d_kn = nullptr; double* d_row = nullptr; int* d_nopos = nullptr; uint8_t* d_nobits = nullptr;
-        std::vector<int> nopos(c->K, -1);
-        const int64_t rowlen = c->Lc + c->S;
-        HIPCHK(c, upload(&d_kn, c->known_pts.data(), c->known_pts.size()));
-        HIPCHK(c, upload(&d_nopos, nopos.data(), nopos.size()));
-        HIPCHK(c, hipMalloc((void**)&d_row, rowlen * sizeof(double)));
-        HIPCHK(c, hipMalloc((void**)&d_nobits, 16));
-        HIPCHK(c, hipMalloc((void**)&c->d_known_time, c->S * sizeof(double)));
-        HIPCHK(c, hipMemset(c->d_known_time, 0, c->S * sizeof(double)));
-        TxArgs k = a;
-        k.P = 0; k.D = 1; k.C = 0; k.pos = d_nopos; k.contig_lo = 0; k.filler = d_kn; k.known_time = c->d_known_time;
-        k.bits = d_nobits; k.row_bytes = 0; k.gaps = nullptr; k.out = d_row; k.stride = rowlen; k.out_dt = DT_F64;
-        int rc = tx_launch(c, k, 1, st);
-        if (rc != GF3_OK) return rc;
-        HIPCHK(c, hipStreamSynchronize(st));
-        std::vector<double> h(c->S);
-        HIPCHK(c, hipMemcpy(h.data(), d_row + c->Lc, c->S * sizeof(double), hipMemcpyDeviceToHost));
-        for (auto& x : h) x *= 0.5;                      // stored before the x2 gain
-        HIPCHK(c, hipMemcpy(c->d_known_time, h.data(), c->S * sizeof(double), hipMemcpyHostToDevice));
-        (void)hipFree(d_kn); (void)hipFree(d_row); (void)hipFree(d_nopos); (void)hipFree(d_nobits);
-    }
     a.P = g.P; a.D = g.D; a.C = g.C; a.contig_lo = c->contig_lo; a.filler = (const cplx*)d_filler_c128;
     a.known_time = c->d_known_time; a.bits = d_bits_packed; a.row_bytes = c->row_bytes; a.gaps = d_gaps;
     a.out = d_out; a.stride = stride; a.out_dt = out_dtype == GF3_F32 ? DT_F32 : DT_F64;
