@@ -12,7 +12,8 @@ LIB = os.path.join(HERE, "lib", "libgf3rx.so")
 
 
 def lib_path():
-    return LIB
+    """In-tree library; GF3_LIB=/path/to/other.so selects another build (A/B timing, diagnostic stamp builds)."""
+    return os.environ.get("GF3_LIB") or LIB
 
 
 def stale():

@@ -4,8 +4,6 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, ctypes as C
-from gf3_audio_modem_amd import build
-if os.environ.get("GF3_LIB"): build.LIB = os.environ["GF3_LIB"]
 from gf3_audio_modem_amd import Engine, RxConfig, qpsk_table
 
 N, CP, P, D, F = 4096, 512, 2, 8, 16384
