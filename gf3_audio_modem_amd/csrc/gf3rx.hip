@@ -206,8 +206,8 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     constexpr int T = NC / 8;
     cplx* lds = smem;
     double* scratch = (double*)(smem + DemodOcc<NC, MODE>::LDS_ELEMS);    // 32 doubles
-    cplx* rtab = (cplx*)(scratch + 32);                                   // [3][64 + NC/64 + 1] rotation tables
-    uint8_t* labs = (uint8_t*)(rtab + 3 * (64 + NC / 64 + 1));            // [2][C] decisions, one byte each
+    cplx* rtab = (cplx*)(scratch + 32);                                   // [2][64 + NC/64 + 1] start-up rotation tables
+    uint8_t* labs = (uint8_t*)(rtab + 2 * (64 + NC / 64 + 1));            // [2][C] decisions, one byte each
     const int tid = threadIdx.x;
     const int64_t f = blockIdx.x;
     const int K = a.K, P = a.P, D = a.D, S = a.S;
@@ -428,44 +428,40 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     };
     const double denom = (double)(D + P);
     const double qq = a.qpsk_q;
-    // Two-level table of carrier-index rotations exp(j phi_l n):  n + 1 = 64 h + i  ->
-    // rot(n) = TH[h] * TL[i],  TL[i] = exp(j phi (i-1)),  TH[h] = exp(j phi 64 h).
-    // phi_l = slope (l + P/2)/(D+P) is linear in l, so the table of symbol l is the table of
-    // symbol l-1 times a fixed per-packet step table (no sin/cos inside the symbol loop).
-    // rtab: [cur 0][cur 1][step], double-buffered on l & 1 (readers of l-1 may still be running).
+    // Channel-model phasor per carrier: Hest = mag * g_l,  g_l = u exp(j slope n f_l),  f_l = (l + P/2)/(D+P)
+    // is linear in l, so g_{l+1} = g_l * exp(j slope n / (D+P)): one complex multiply per carrier per symbol
+    // and no sin/cos inside the symbol loop.  The two start-up rotations exp(j phi0 n), exp(j dphi n) come
+    // from small two-level tables (n + 1 = 64 h + i  ->  T[64 + h] * T[i]) built once per packet.
     constexpr int NTH = NC / 64 + 1, NRT = 64 + NTH;
     {
         const double phi0 = slope * ((0.5 * (double)P) / denom), dphi = slope / denom;
-        for (int i = launder(tid); i < NRT; i += T) {
+        for (int i = tid; i < NRT; i += T) {
             const double nn = (double)(i < 64 ? i - 1 : 64 * (i - 64));
             rtab[i] = cis_fast(phi0 * nn);
-            rtab[2 * NRT + i] = cis_fast(dphi * nn);
+            rtab[NRT + i] = cis_fast(dphi * nn);
         }
     }
-    auto build_rot = [&](int l) {                     // table for symbol l (l >= 1) from symbol l-1
-        if (l == 0) return;
-        const cplx* prev = rtab + ((l - 1) & 1) * NRT;
-        cplx* cur = rtab + (l & 1) * NRT;
-        // done by the upper half of the block: the lower half packs the previous symbol's bits
-        for (int i = (launder(tid) + T / 2) % T; i < NRT; i += T) cur[i] = cmul(prev[i], rtab[2 * NRT + i]);
-    };
-    auto rot_of = [&](const cplx* tb, int n) {
-        const int n1 = n + 1;
-        return cmul(tb[64 + (n1 >> 6)], tb[n1 & 63]);
-    };
+    lds_barrier();
+    cplx gstep[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int n1 = bin_of(s);                                          // n + 1
+        const cplx r0 = cmul(rtab[64 + (n1 >> 6)], rtab[n1 & 63]);
+        gstep[s] = cmul(rtab[NRT + 64 + (n1 >> 6)], rtab[NRT + (n1 & 63)]);
+        u[s] = cmul(u[s], r0);                                             // u now holds g_0
+    }
     for (int l = 0; l < D; ++l) {
-        build_rot(l);
         if constexpr (SPECTRA) { lds_barrier(); load_spectra(a.sp_data + ((int64_t)f * D + l) * K); }
         else transform(2 * P + l);
         if (l > 0) pack_words(l - 1, false);
         const double fl = ((double)l + 0.5 * (double)P) / denom;          // (l + P/2)/(D+P)
-        const cplx* tb = rtab + (l & 1) * NRT;
         uint8_t* lab_l = labs + (l & 1) * C;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int n = bin_of(s) - 1;
-            const cplx g = cmul(u[s], rot_of(tb, n));                      // unit phasor of Hest
+            const cplx g = u[s];                                           // unit phasor of Hest for this symbol
             const cplx ep = cmul_conj(v[s], g);                            // X / g  = e * mag
+            u[s] = cmul(g, gstep[s]);                                      // ... and for the next one
             const int ps = pos_of(s);
             if constexpr (MODE == MODE_QPSK) {
                 if (ps >= 0) lab_l[ps] = (uint8_t)qpsk_sign_rule(ep);
@@ -1342,7 +1338,7 @@ extern "C" int gf3_rfft_batch(gf3_ctx* c, const void* d_in, int64_t n_in, const 
 
 static size_t demod_lds_bytes(const gf3_ctx* c, bool lean = false) {
     const bool inplace = lean && GF3_DEMOD_WPS > 2 && c->NC <= 2048;
-    return (inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC)) + 32 * sizeof(double) + (size_t)3 * (64 + c->NC / 64 + 1) * sizeof(cplx) +
+    return (inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC)) + 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) +
            (size_t)((2 * c->cfg.C + 15) & ~15);
 }
 
