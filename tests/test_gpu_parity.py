@@ -434,3 +434,24 @@ def test_schmidl_cox_metric():
     assert rx.schmidlcox_method(r.astype(np.float64)) == int(g["index"])
     with pytest.raises(IndexError):
         rx.schmidlcox_method(r[:5000])
+
+
+def test_real_recording_symbols_full_mode():
+    """Reference default geometry (P=20, D=180, 3 packets) on the real recording: equalised symbols of the
+    full-dump mode against the oracle -- 180 steps of the per-carrier phasor recurrence, 20 pilots averaged
+    in the time domain -- and the bits-only mode against the full mode."""
+    g = load("g6_realrec")
+    p = modeA2_params(g["known_bits"])
+    r = g["wav_u8"] / 1.0
+    ref = orc.receive(r, p)
+    eng = engine_for(p)
+    x = torch.from_numpy(r).cuda()
+    starts = torch.from_numpy(ref["starts"]).cuda()
+    full = eng.demod_frames(x, starts, want=("eq", "Hest", "slope"))
+    scale = float(np.abs(ref["eq"]).max())
+    assert np.abs(full["eq"].cpu().numpy() - ref["eq"]).max() <= 1e-9 * scale
+    assert np.abs(full["Hest"].cpu().numpy() - ref["Hest"]).max() <= 1e-10 * np.abs(ref["Hest"]).max()
+    np.testing.assert_allclose(full["slope"].cpu().numpy(), ref["slope"], rtol=0, atol=1e-12)
+    lean = eng.demod_frames(x, starts)
+    assert torch.equal(lean["bits"], full["bits"])
+    assert np.array_equal(eng.unpack_bits(lean["bits"]).cpu().numpy(), ref["bits"])
