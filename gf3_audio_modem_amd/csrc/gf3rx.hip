@@ -262,11 +262,6 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     };
     GF3_STAMP(0);
     if constexpr (!SPECTRA) fetch(0);
-    cplx ik[8];                                       // 1/known for this thread's carriers, needed after the pilots;
-#pragma unroll                                        // loaded now so the L2 latency hides under the pilot transforms
-    for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
-#pragma unroll                                        // pin them here: without a use the compiler sinks these loads
-    for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(ik[s].x), "v"(ik[s].y));   // to the finalize stage again
 
     // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451).
     // The mean of the P pilot spectra is the spectrum of the mean pilot symbol (the DFT is linear), so
@@ -317,9 +312,12 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     double* ph0 = (double*)lds;
     double* ph1 = ph0 + NC;
     cplx u[8];
-    double a0[8], da[8], p0[8], p1[8];
+    double a0[8], da[8];
     const double invP = 1.0 / (double)P;
     // (a) straight-line over the 8 slots (independent chains overlap): H = mean/known, unit phasor, magnitudes
+    cplx ik[8];                                       // 1/known (L2 latency covered by the other resident workgroup)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         Hs[s] = cmul(cscale(Hs[s], invP), ik[s]);
@@ -332,7 +330,6 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
             da[s] = e2 * rsq_nr(e2) - a0[s];                          // |He| - |Hs|
         }
         u[s] = cmk(Hs[s].x * ia, Hs[s].y * ia);
-        p0[s] = 0.0; p1[s] = 0.0;
     }
     // (b) optional dumps and the angles of the carriers inside the fit range
 #pragma unroll
@@ -342,10 +339,8 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
             if (a.Hs) a.Hs[f * K + bn - 1] = Hs[s];
             if (a.He) a.He[f * K + bn - 1] = He[s];
             if (bn - 1 >= a.fit_lo && bn - 1 < a.fit_hi) {
-                p0[s] = atan2_fast(Hs[s].y, Hs[s].x);
-                p1[s] = atan2_fast(He[s].y, He[s].x);
-                ph0[bn - 1] = p0[s];
-                ph1[bn - 1] = p1[s];
+                ph0[bn - 1] = atan2_fast(Hs[s].y, Hs[s].x);
+                ph1[bn - 1] = atan2_fast(He[s].y, He[s].x);
             }
         }
     }
@@ -359,10 +354,11 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
             const int n = bin_of(s) - 1;
             if (live_of(s) && n >= a.fit_lo && n < a.fit_hi) {
                 const int j = n - a.fit_lo;
-                acc += ((double)j - a.xbar) * (p1[s] - p0[s]);
+                const double q0 = ph0[n], q1 = ph1[n];               // this thread's own angles, back from LDS
+                acc += ((double)j - a.xbar) * (q1 - q0);
                 if (j > 0) {
-                    const double e0 = unwrap_corr(p0[s] - ph0[n - 1]);
-                    const double e1 = unwrap_corr(p1[s] - ph1[n - 1]);
+                    const double e0 = unwrap_corr(q0 - ph0[n - 1]);
+                    const double e1 = unwrap_corr(q1 - ph1[n - 1]);
                     acc += (e1 - e0) * (0.5 * (double)j * (double)(L - j));
                 }
             }
