@@ -308,9 +308,12 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     // so the fit needs no prefix scan, and corrections before fit_lo (a common offset of every
     // fitted point) drop out: only carriers inside the fit range need their angles.
     GF3_STAMP(2);
-    lds_barrier();                                    // FFT buffer is free: reuse it for the phases
-    double* ph0 = (double*)lds;
-    double* ph1 = ph0 + NC;
+    lds_barrier();                                    // FFT buffer is free: reuse it for the fit-range carriers
+    const int L = a.fit_hi - a.fit_lo;
+    // [L] Hs of carrier fit_lo + j, later its angle in .x: in the FFT buffer when it holds 2 L points, else behind
+    // the decision bytes (demod_lds_bytes sizes the allocation for that)
+    cplx* hsl = (2 * L <= DemodOcc<NC, MODE>::LDS_ELEMS) ? lds : (cplx*)(labs + ((2 * a.C + 15) & ~15));
+    cplx* hel = hsl + L;                              // [L] same for He
     cplx u[8];
     double a0[8], da[8];
     const double invP = 1.0 / (double)P;
@@ -331,36 +334,35 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         }
         u[s] = cmk(Hs[s].x * ia, Hs[s].y * ia);
     }
-    // (b) optional dumps and the angles of the carriers inside the fit range
+    // (b) optional dumps; the carriers inside the fit range go to LDS, where the angles are taken by
+    //     whichever thread the carrier falls to (2 L angles per packet instead of 16 per thread)
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int bn = bin_of(s);
         if (live_of(s)) {
             if (a.Hs) a.Hs[f * K + bn - 1] = Hs[s];
             if (a.He) a.He[f * K + bn - 1] = He[s];
-            if (bn - 1 >= a.fit_lo && bn - 1 < a.fit_hi) {
-                ph0[bn - 1] = atan2_fast(Hs[s].y, Hs[s].x);
-                ph1[bn - 1] = atan2_fast(He[s].y, He[s].x);
-            }
+            const int j = bn - 1 - a.fit_lo;
+            if (j >= 0 && j < L) { hsl[j] = Hs[s]; hel[j] = He[s]; }
         }
+    }
+    lds_barrier();
+    for (int j = launder(tid); j < L; j += T) {
+        const cplx h0 = hsl[j], h1 = hel[j];
+        hsl[j].x = atan2_fast(h0.y, h0.x);
+        hel[j].x = atan2_fast(h1.y, h1.x);
     }
     lds_barrier();
     double slope;
     {
         double acc = 0.0;
-        const int L = a.fit_hi - a.fit_lo;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int n = bin_of(s) - 1;
-            if (live_of(s) && n >= a.fit_lo && n < a.fit_hi) {
-                const int j = n - a.fit_lo;
-                const double q0 = ph0[n], q1 = ph1[n];               // this thread's own angles, back from LDS
-                acc += ((double)j - a.xbar) * (q1 - q0);
-                if (j > 0) {
-                    const double e0 = unwrap_corr(q0 - ph0[n - 1]);
-                    const double e1 = unwrap_corr(q1 - ph1[n - 1]);
-                    acc += (e1 - e0) * (0.5 * (double)j * (double)(L - j));
-                }
+        for (int j = launder(tid); j < L; j += T) {
+            const double q0 = hsl[j].x, q1 = hel[j].x;
+            acc += ((double)j - a.xbar) * (q1 - q0);
+            if (j > 0) {
+                const double e0 = unwrap_corr(q0 - hsl[j - 1].x);
+                const double e1 = unwrap_corr(q1 - hel[j - 1].x);
+                acc += (e1 - e0) * (0.5 * (double)j * (double)(L - j));
             }
         }
         slope = block_sum(acc, scratch + 16) * a.inv_sxx;
@@ -446,6 +448,14 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         gstep[s] = cmul(rtab[NRT + 64 + (n1 >> 6)], rtab[NRT + (n1 & 63)]);
         u[s] = cmul(u[s], r0);                                             // u now holds g_0
     }
+    // data position of every slot, resolved once: a lookup inside the symbol loop would put a vmcnt(0) wait
+    // behind the packed-word stores and the next symbol's prefetch
+    // (QPSK mode; the other modes have no registers to spare for it)
+    int psl[8];
+    if constexpr (MODE == MODE_QPSK) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) psl[s] = pos_of(s);
+    }
     for (int l = 0; l < D; ++l) {
         if constexpr (SPECTRA) { lds_barrier(); load_spectra(a.sp_data + ((int64_t)f * D + l) * K); }
         else transform(2 * P + l);
@@ -458,7 +468,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
             const cplx g = u[s];                                           // unit phasor of Hest for this symbol
             const cplx ep = cmul_conj(v[s], g);                            // X / g  = e * mag
             u[s] = cmul(g, gstep[s]);                                      // ... and for the next one
-            const int ps = pos_of(s);
+            const int ps = (MODE == MODE_QPSK) ? psl[s] : pos_of(s);
             if constexpr (MODE == MODE_QPSK) {
                 if (ps >= 0) lab_l[ps] = (uint8_t)qpsk_sign_rule(ep);
                 if (s & 1) __builtin_amdgcn_sched_barrier(0);   // two carriers at a time: bounds the loads in flight
@@ -1060,6 +1070,9 @@ static size_t fft_lds_bytes(int NC) {          // == FftGeom<NC>::LDS_ELEMS
 template <typename Kern, typename Args>
 static hipError_t launch(Kern k, int64_t grid, int threads, size_t lds, hipStream_t st, const Args& a) {
     if (grid <= 0) return hipSuccess;
+#ifdef GF3_LDS_PAD      /* diagnostic builds only: extra dynamic LDS to force a lower occupancy */
+    lds += GF3_LDS_PAD;
+#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1334,8 +1347,10 @@ extern "C" int gf3_rfft_batch(gf3_ctx* c, const void* d_in, int64_t n_in, const 
 
 static size_t demod_lds_bytes(const gf3_ctx* c, bool lean = false) {
     const bool inplace = lean && GF3_DEMOD_WPS > 2 && c->NC <= 2048;
-    return (inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC)) + 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) +
-           (size_t)((2 * c->cfg.C + 15) & ~15);
+    const size_t fft = inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC);
+    const size_t fit = (size_t)2 * (c->fit_hi - c->fit_lo) * sizeof(cplx);      // Hs, He of the fit-range carriers
+    return fft + 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) +
+           (size_t)((2 * c->cfg.C + 15) & ~15) + (fit > fft ? fit : 0);
 }
 
 extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,
