@@ -563,14 +563,21 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         for (int r = 0; r < 8; ++r) v[r] = nxt[r].get();
         if (q + 1 < a.Q) fetch(q + 1);
         const int tq = tid;
+        // this partition's chirp spectrum, requested before the transform: the barriers' memory clobber keeps the
+        // compiler from moving these loads up itself, and their L2 latency would sit between transform and MAC
+        cplx hq[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec<NC>::bin(tq, s)];
+        double h0 = 0.0, hN = 0.0;
+        if (tid == 0) { h0 = Hq[0].x; hN = Hq[NC].x; }
         ft.refresh();
         asm volatile("" : "+v"(wb.x), "+v"(wb.y));
         rfft_regs<NC, PP>(v, lds, ft, wb, tq, z0, q & 1);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc[s] = cadd(acc[s], cmul_conj(v[s], Hq[Spec<NC>::bin(tq, s)]));
+        for (int s = 0; s < 8; ++s) acc[s] = cadd(acc[s], cmul_conj(v[s], hq[s]));
         if (tid == 0) {
-            accDC += (z0.x + z0.y) * Hq[0].x;
-            accNy += (z0.x - z0.y) * Hq[NC].x;
+            accDC += (z0.x + z0.y) * h0;
+            accNy += (z0.x - z0.y) * hN;
         }
     }
     // ---- inverse real FFT of the accumulated Hermitian spectrum Y

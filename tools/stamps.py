@@ -33,8 +33,26 @@ print("median block lifetime (s_memtime ticks):", np.median(tot))
 for i, nme in enumerate(names):
     print(f"  {nme:32s} median {np.median(d[:, i]):10.0f}  share {np.median(d[:, i]) / np.median(tot):6.1%}")
 
-# finer stamps inside finalize when present (slots 6, 7 of a build that sets them)
+# slots 6, 7: s_memrealtime (100 MHz) at the first and last stamp of the packet -> shader clock and wall time
 if s[:, 6].max() > 0:
-    print("  finalize: per-carrier H/angles   median", np.median(s[:, 6] - s[:, 2]))
-    print("  finalize: barrier + slope sums   median", np.median(s[:, 7] - s[:, 6]))
-    print("  finalize: rotation-table init    median", np.median(s[:, 3] - s[:, 7]))
+    wall = (s[:, 7] - s[:, 6]) * 10.0                       # ns
+    print(f"packet wall time median {np.median(wall) / 1e3:.2f} us; shader clock {np.median(tot / wall) * 1e3:.0f} MHz")
+    print(f"first stamp -> last stamp over the whole launch: {(s[:, 7].max() - s[:, 6].min()) * 10.0 / 1e6:.3f} ms for {F} packets")
+
+# persistent kernels: packets f, f + G, f + 2G ... belong to one workgroup (G = resident grid)
+G = int(os.environ.get("GF3_STAMPS_GRID", "0"))
+if G:
+    r0 = s[:, 6].reshape(-1, G) * 10.0      # [round, workgroup] ns
+    r1 = s[:, 7].reshape(-1, G) * 10.0
+    gap = r0[1:] - r1[:-1]
+    print(f"persistent grid {G}: gap between packets of one workgroup: median {np.median(gap) / 1e3:.2f} us, p90 {np.percentile(gap, 90) / 1e3:.2f} us")
+    t_end = r1[-1] - r0[0].min()
+    t_beg = r0[0] - r0[0].min()
+    print(f"  workgroup start skew: median {np.median(t_beg) / 1e3:.1f} us, max {t_beg.max() / 1e3:.1f} us; finish: min {t_end.min() / 1e3:.1f} median {np.median(t_end) / 1e3:.1f} max {t_end.max() / 1e3:.1f} us")
+    per = (r1 - r0)
+    print(f"  packet wall time by round (median over workgroups, us):", np.round(np.median(per, axis=1) / 1e3, 1)[:40])
+    fin = r1[-1] - r0[0].min()
+    print("  finish time (us) by XCD (blockIdx % 8):", np.round([np.median(fin[x::8]) / 1e3 for x in range(8)], 0))
+    print("  finish time (us) by grid half:", np.round([np.median(fin[:G // 2]) / 1e3, np.median(fin[G // 2:]) / 1e3], 0))
+    within = fin.reshape(-1, 8)            # [slot in XCD, XCD]
+    print("  finish time (us) by position inside XCD 0 (blockIdx // 8):", np.round(within[:, 0] / 1e3, 0))
