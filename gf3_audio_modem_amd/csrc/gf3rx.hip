@@ -204,10 +204,11 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     constexpr bool FULL = (MODE == MODE_FULL);
     extern __shared__ double2 smem[];
     constexpr int T = NC / 8;
-    cplx* lds = smem;
-    double* scratch = (double*)(smem + DemodOcc<NC, MODE>::LDS_ELEMS);    // 32 doubles
-    cplx* rtab = (cplx*)(scratch + 32);                                   // [2][64 + NC/64 + 1] start-up rotation tables
-    uint8_t* labs = (uint8_t*)(rtab + 2 * (64 + NC / 64 + 1));            // [2][C] decisions, one byte each
+    // LDS: [scratch 32 doubles | start-up rotation tables | FFT buffer | decision bytes | (fit-range overflow)]
+    double* scratch = (double*)smem;
+    cplx* rtab = (cplx*)(scratch + 32);                                   // [2][64 + NC/64 + 1]
+    cplx* lds = rtab + 2 * (64 + NC / 64 + 1);                            // FFT buffer, DemodOcc::LDS_ELEMS points
+    uint8_t* labs = (uint8_t*)(lds + DemodOcc<NC, MODE>::LDS_ELEMS);      // [2][C] decisions, one byte each
     const int tid = threadIdx.x;
     const int64_t f = blockIdx.x;
     const int K = a.K, P = a.P, D = a.D, S = a.S;
@@ -310,9 +311,9 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     GF3_STAMP(2);
     lds_barrier();                                    // FFT buffer is free: reuse it for the fit-range carriers
     const int L = a.fit_hi - a.fit_lo;
-    // [L] Hs of carrier fit_lo + j, later its angle in .x: in the FFT buffer when it holds 2 L points, else behind
-    // the decision bytes (demod_lds_bytes sizes the allocation for that)
-    cplx* hsl = (2 * L <= DemodOcc<NC, MODE>::LDS_ELEMS) ? lds : (cplx*)(labs + ((2 * a.C + 15) & ~15));
+    // [L] Hs of carrier fit_lo + j, later its angle in .x.  The two arrays start at the FFT buffer and may run on
+    // over the decision bytes (not in use before the first data symbol) and beyond: demod_lds_bytes sizes it.
+    cplx* hsl = lds;
     cplx* hel = hsl + L;                              // [L] same for He
     cplx u[8];
     double a0[8], da[8];
@@ -1355,9 +1356,9 @@ extern "C" int gf3_rfft_batch(gf3_ctx* c, const void* d_in, int64_t n_in, const 
 static size_t demod_lds_bytes(const gf3_ctx* c, bool lean = false) {
     const bool inplace = lean && GF3_DEMOD_WPS > 2 && c->NC <= 2048;
     const size_t fft = inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC);
-    const size_t fit = (size_t)2 * (c->fit_hi - c->fit_lo) * sizeof(cplx);      // Hs, He of the fit-range carriers
-    return fft + 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) +
-           (size_t)((2 * c->cfg.C + 15) & ~15) + (fit > fft ? fit : 0);
+    const size_t tail = fft + (size_t)((2 * c->cfg.C + 15) & ~15);              // FFT buffer + decision bytes ...
+    const size_t fit = (size_t)2 * (c->fit_hi - c->fit_lo) * sizeof(cplx);      // ... overlaid by Hs, He of the fit range
+    return 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) + (fit > tail ? fit : tail);
 }
 
 extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,

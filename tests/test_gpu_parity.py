@@ -87,7 +87,7 @@ def test_narrow_sample_storage(name, dt):
     peaks = eng.sync_stream(x)
     assert np.array_equal(peaks.cpu().numpy(), np.flatnonzero(ref["zeros"]))
     o = eng.demod_frames(x, (peaks + 2)[:-1], want=("eq",))
-    assert np.array_equal(eng.unpack_bits(o["bits"]).cpu().numpy(), ref["bits"])
+    assert np.array_equal(eng.unpack_bits(o["bits"]).cpu().numpy().reshape(-1), ref["bits"].reshape(-1))
     scale = max(1.0, float(np.abs(ref["eq"]).max()))
     assert np.abs(o["eq"].cpu().numpy() - ref["eq"]).max() <= 1e-9 * scale
 
@@ -123,6 +123,37 @@ def test_sync_frames_batched(N, CP, mu):
     np.testing.assert_allclose(peak.cpu().numpy(), np.full(F, np.dot(c, c)), rtol=1e-6)
     o = eng.demod_frames(x, starts, want=())
     assert np.array_equal(eng.unpack_bits(o["bits"]).cpu().numpy(), payload)   # noiseless => BER 0
+
+
+@pytest.mark.parametrize("N,CP", [(1024, 128), (2048, 256), (4096, 512), (8192, 1024)])
+def test_phase_slope_over_whole_band(N, CP):
+    """Fit range = every carrier ([0:K]): the fit-range carriers no longer fit the FFT buffer for N = 1024 and
+    8192 (they move behind the decision bytes) and fill it exactly for N = 4096.  Drifted, echoey stream;
+    slope, channel estimates, equalised symbols and bits against the oracle in full mode, bits in lean mode."""
+    pts, bt = orc.qpsk_table()
+    K = N // 2 - 1
+    known = load("g6_realrec")["known_bits"]
+    known = np.tile(known, -(-K * 2 // len(known)))
+    p = orc.RxParams(N=N, CP=CP, P=2, D=3, lo=1, hi=K, const_points=pts, const_bits=bt, known_bits=known,
+                     fit_lo=0, fit_hi=K)
+    F = 3
+    rows, gaps, payload = _rows_with_gaps(p, F, seed=7 * N)
+    rs = np.random.RandomState(N)
+    h = np.zeros(40); h[0] = 1.0; h[3] = -0.35; h[17] = 0.2; h[39] = 0.08          # echoes inside the prefix
+    x = np.concatenate([np.convolve(rows[f], h)[: rows.shape[1]] for f in range(F)])
+    x = x + 0.01 * rs.randn(len(x))
+    starts = np.arange(F) * rows.shape[1] + gaps + p.Lc + 1                        # one sample late: a phase ramp
+    ref = orc.demod_frames(x, starts, p)
+    eng = engine_for(p)
+    xd = torch.from_numpy(x).cuda()
+    o = eng.demod_frames(xd, starts, want=("eq", "Hs", "He", "slope"))
+    np.testing.assert_allclose(o["slope"].cpu().numpy(), ref["slope"], rtol=0, atol=1e-11)
+    assert np.abs(o["Hs"].cpu().numpy() - ref["Hs"]).max() <= 1e-10
+    assert np.abs(o["He"].cpu().numpy() - ref["He"]).max() <= 1e-10
+    assert np.abs(o["eq"].cpu().numpy().reshape(ref["eq"].shape) - ref["eq"]).max() <= 1e-6
+    assert np.array_equal(eng.unpack_bits(o["bits"]).cpu().numpy().reshape(-1), ref["bits"].reshape(-1))
+    lean = eng.demod_frames(xd, starts, want=())
+    assert torch.equal(lean["bits"], o["bits"])
 
 
 def test_sync_frames_window_rule_matches_oracle_on_multipath():
