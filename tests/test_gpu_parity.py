@@ -316,6 +316,35 @@ def test_config3_16qam_gr5_stream():
     assert np.abs(o2["eq"].cpu().numpy() - ref32["eq"]).max() <= 1e-9 * max(1, np.abs(ref32["eq"]).max())
 
 
+def test_config3_full_size_stream():
+    """BASELINE config 3 at full size (tools/config3.py: 4 096 16-QAM packets as one 321 M-sample stream through the
+    measured channel): sync offsets exact, and the first packets and the three WORST packets (where the
+    reference's unwrap/slope model struggles in the channel's nulls) bit-identical to the oracle on the same
+    samples -- parity is about matching the reference, not about BER."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("config3_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "config3.py"))
+    tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
+    eng, cfg, channel = tool.make_engine()
+    F = 4096
+    r, payload = tool.make_stream(eng, channel, F)
+    res, starts, out = tool.measure(eng, cfg, r, payload, reps=1)
+    assert res["sync_offsets_as_expected_plus1"]
+    pts, bt = orc.square_qam_table(4)
+    known = load("g3_n4096_16qam_gr5")["known_bits"].astype(np.uint8)
+    p = orc.RxParams(N=4096, CP=512, P=2, D=8, lo=1, hi=2047, const_points=pts, const_bits=bt.astype(np.int64), known_bits=known)
+    m = 4
+    seg = r[: 64 + (m + 1) * cfg.frame_len + 4000].cpu().numpy().astype(np.float64)
+    ref = orc.demod_frames(seg, starts[:m].cpu().numpy(), p)["bits"]
+    got = np.unpackbits(out[:m].cpu().numpy(), axis=1)[:, : cfg.bits_per_frame].reshape(-1)
+    assert np.array_equal(ref, got)
+    for f in res["worst_packets"]:
+        s0 = int(starts[f].item())
+        seg2 = r[s0 - 100: s0 + cfg.M * cfg.S + 100].cpu().numpy().astype(np.float64)
+        ref2 = orc.demod_frames(seg2, np.array([100]), p)["bits"]
+        assert np.array_equal(ref2, np.unpackbits(out[f].cpu().numpy())[: cfg.bits_per_frame])
+    assert 0.0 < res["ber"] < 0.05
+
+
 def test_lean_modes_agree_with_full_on_noisy_qpsk():
     """MODE_QPSK (sign rule, no magnitudes) == MODE_FULL (literal scan on equalised symbols) on noisy data,
     and an all-zero packet (exact ties everywhere) decodes as the reference's argmin does: label 00."""
