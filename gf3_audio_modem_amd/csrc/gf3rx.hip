@@ -647,6 +647,7 @@ struct OlsArgs {
     cplx* spec;               // [NWIN][NC+1]
     int64_t nwin, plen;
     double* corr;
+    double* part;             // [ols grid] maximum of the lags each workgroup wrote (the global max is max over these)
 };
 
 template <int NC, int DT>
@@ -722,6 +723,7 @@ __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
         }
     }
     const double inv = 1.0 / (double)NC;
+    double mx = -INFINITY;                            // max of the lags this workgroup writes (OFDM.py:359 needs max(P))
     for (int g = 0; g < 2; ++g) {
         const int64_t m0 = (b + g) * (int64_t)a.H;
         if (m0 >= a.plen) break;
@@ -754,10 +756,14 @@ __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
         const int W = left < a.H ? (int)left : a.H;
         for (int i = tid; 2 * i < W; i += T) {        // y[2n] = Re z / NC, y[2n+1] = -Im z / NC
             const cplx z = yb[i];
-            a.corr[m0 + 2 * i] = z.x * inv;
-            if (2 * i + 1 < W) a.corr[m0 + 2 * i + 1] = -z.y * inv;
+            const double y0 = z.x * inv, y1 = -z.y * inv;
+            a.corr[m0 + 2 * i] = y0;
+            mx = fmax(mx, y0);
+            if (2 * i + 1 < W) { a.corr[m0 + 2 * i + 1] = y1; mx = fmax(mx, y1); }
         }
     }
+    mx = block_max(mx, (double*)lds);                 // (starts with a barrier: every wave is done reading yb)
+    if (tid == 0) a.part[blockIdx.x] = mx;
 }
 
 // ============================================================================
@@ -766,14 +772,6 @@ __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
 #define PK_THREADS 256
 #define PK_ITEMS 8
 
-__global__ void pk_max_partial(const double* __restrict__ P, int64_t len, double* partial) {
-    __shared__ double scratch[16];
-    double mx = -INFINITY;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x)
-        mx = fmax(mx, P[i]);
-    mx = block_max(mx, scratch);
-    if (threadIdx.x == 0) partial[blockIdx.x] = mx;
-}
 __global__ void pk_max_final(const double* partial, int n, double* out) {
     __shared__ double scratch[16];
     double mx = -INFINITY;
@@ -781,21 +779,36 @@ __global__ void pk_max_final(const double* partial, int n, double* out) {
     mx = block_max(mx, scratch);
     if (threadIdx.x == 0) out[0] = mx;
 }
-GF3_DEV bool pk_is_cand(const double* __restrict__ P, int64_t i, double mx, double thresh) {
-    const double p0 = P[i] / mx, p1 = P[i + 1] / mx, p2 = P[i + 2] / mx;
-    return ((p1 - p0) * (p2 - p1) <= 0.0) && (p1 > thresh);
-}
-// pass 0: count per block; pass 1: write ascending indices at the block's offset
+// pass 0: count per block; pass 1: write ascending indices at the block's offset (blocks that counted none return
+// at once, and candidates are a handful per chirp, so the second pass costs next to nothing).
+// Candidate at i  <=>  (p1-p0)(p2-p1) <= 0 and p1 > thresh with p = P/max (OFDM.py:359-361: the division is done
+// first there, so it is done here too -- one correctly rounded division per lag, shared by its three uses).
+// Lags that cannot reach the threshold skip the divisions: P1 < thresh*max*(1-1e-6) implies fl(P1/max) < thresh.
 __global__ void pk_candidates(const double* __restrict__ P, int64_t nz, const double* mxp, double thresh,
                               int64_t* counts, const int64_t* offsets, int64_t* cand) {
     __shared__ int wsum[PK_THREADS / 64];
+    if (offsets && counts[blockIdx.x] == 0) return;
     const double mx = mxp[0];
+    const bool filt = mx > 0.0 && thresh > 0.0 && mx < INFINITY && thresh < INFINITY;
+    const double lim = filt ? thresh * mx * (1.0 - 1e-6) : -INFINITY;
     const int64_t base = ((int64_t)blockIdx.x * PK_THREADS + threadIdx.x) * PK_ITEMS;
     int c = 0;
     unsigned flags = 0;
-    for (int k = 0; k < PK_ITEMS; ++k) {
-        const int64_t i = base + k;
-        if (i < nz && pk_is_cand(P, i, mx, thresh)) { flags |= 1u << k; ++c; }
+    if (base < nz) {
+        double q[PK_ITEMS + 2];                       // P[base .. base+PK_ITEMS+1] (nz = len - 2: always inside P when i < nz)
+        const int cnt = (nz - base < PK_ITEMS) ? (int)(nz - base) : PK_ITEMS;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < PK_ITEMS + 2; ++k) q[k] = (k < cnt + 2) ? P[base + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < PK_ITEMS; ++k) any = any || (k < cnt && !(q[k + 1] < lim));
+        if (any) {
+#pragma unroll
+            for (int k = 0; k < PK_ITEMS + 2; ++k) q[k] = q[k] / mx;
+#pragma unroll
+            for (int k = 0; k < PK_ITEMS; ++k)
+                if (k < cnt && ((q[k + 1] - q[k]) * (q[k + 2] - q[k + 1]) <= 0.0) && (q[k + 1] > thresh)) { flags |= 1u << k; ++c; }
+        }
     }
     // block-wide exclusive scan of c
     int x = c;
@@ -831,34 +844,48 @@ __global__ void pk_scan(const int64_t* counts, int64_t n, int64_t* offsets, int6
     }
     if (threadIdx.x == 0) total[0] = carry;
 }
-// sequential suppression (OFDM.py:364-370) over the sorted candidate list, one wave:
-// an accepted candidate i suppresses everything up to i+Lc, so the next survivor is the first
-// candidate >= i+Lc+1; the wave probes 64 list entries per step and ballots for the first hit
-// (the next chirp's cluster is normally within a few entries), falling back to larger strides.
-__global__ void pk_nms(const int64_t* cand, const int64_t* totalp, int64_t Lc, int64_t nz,
-                       int64_t* peaks, int64_t cap, int64_t* npeaks) {
-    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
-    const int lane = threadIdx.x;
+// sequential suppression (OFDM.py:364-370) over the sorted candidate list: an accepted candidate i suppresses
+// everything up to i+Lc, so the next survivor is the first candidate >= i+Lc+1.  One workgroup walks the list in
+// chunks staged in LDS: every thread finds the successor of its candidates by binary search (parallel), then one
+// thread follows the successor chain (one LDS round trip per accepted peak instead of two dependent global loads).
+#define NMS_CHUNK 4096
+#define NMS_THREADS 1024
+GF3_DEV int nms_lower_bound(const int64_t* v, int n, int64_t want) {     // first k in [0, n] with v[k] >= want
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (v[mid] >= want) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+__global__ __launch_bounds__(NMS_THREADS) void pk_nms(const int64_t* cand, const int64_t* totalp, int64_t Lc, int64_t nz,
+                                                      int64_t* peaks, int64_t cap, int64_t* npeaks) {
+    __shared__ int64_t sv[NMS_CHUNK];
+    __shared__ int succ[NMS_CHUNK];
+    __shared__ int64_t st[3];                                            // np, status, want (thread 0 -> all)
     const int64_t total = totalp[0];
-    int64_t pos = 0, np = 0, status = 0;
-    while (pos < total) {
-        const int64_t i = cand[pos];                                 // wave-uniform
-        if (i + Lc >= nz) { np = 0; status = 1; break; }             // the except-branch wipes everything
-        if (lane == 0) { if (np < cap) peaks[np] = i; }
-        if (np >= cap) status = 2;
-        ++np;
-        const int64_t want = i + Lc + 1;
-        int64_t lo = pos + 1;
-        for (;;) {                                                   // first index >= lo with cand >= want
-            const int64_t k = lo + lane;
-            const bool hit = (k >= total) || (cand[k] >= want);
-            const unsigned long long m = __ballot(hit);
-            if (m) { lo += __builtin_ctzll(m); break; }
-            lo += 64;
+    if (threadIdx.x == 0) { st[0] = 0; st[1] = 0; st[2] = INT64_MIN; }
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < total; c0 += NMS_CHUNK) {
+        const int m = (int)((total - c0 < NMS_CHUNK) ? (total - c0) : NMS_CHUNK);
+        for (int k = threadIdx.x; k < m; k += NMS_THREADS) sv[k] = cand[c0 + k];
+        __syncthreads();
+        if (st[1] == 1) break;                                           // wiped: nothing can be accepted any more
+        for (int k = threadIdx.x; k < m; k += NMS_THREADS) succ[k] = nms_lower_bound(sv, m, sv[k] + Lc + 1);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t np = st[0], status = st[1], want = st[2];
+            int k = nms_lower_bound(sv, m, want);
+            while (k < m) {
+                const int64_t i = sv[k];
+                if (i + Lc >= nz) { np = 0; status = 1; break; }         // the except-branch wipes everything
+                if (np < cap) peaks[np] = i; else status = 2;
+                ++np;
+                want = i + Lc + 1;
+                k = succ[k];
+            }
+            st[0] = np; st[1] = status; st[2] = want;
         }
-        pos = lo;
+        __syncthreads();
     }
-    if (lane == 0) { npeaks[0] = np; npeaks[1] = status; }
+    if (threadIdx.x == 0) { npeaks[0] = st[0]; npeaks[1] = st[1]; }
 }
 
 // ============================================================================
@@ -1587,7 +1614,7 @@ struct StreamWs { int64_t plen, nz, nb_max, nb_c, nblk, nwin; size_t o_P, o_part
 static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
     StreamWs w;
     w.plen = n + c->Lc - 1; w.nz = w.plen - 2;
-    w.nb_max = 1024;
+    w.nb_max = ((w.plen + c->stream_plan.Lp - 1) / c->stream_plan.Lp + 1) / 2;      // one partial maximum per ols workgroup
     w.nb_c = (w.nz + PK_THREADS * PK_ITEMS - 1) / (PK_THREADS * PK_ITEMS);
     if (w.nb_c < 1) w.nb_c = 1;
     size_t o = 0;
@@ -1629,7 +1656,7 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
         OlsArgs a{};
         a.t = pl.t; a.in = d_r; a.n_in = n; a.dt = c->cfg.in_dtype;
         a.Hq = pl.d_Hq; a.Q = pl.Q; a.H = pl.Lp; a.Lc = c->Lc;
-        a.spec = (cplx*)(base + w.o_spec); a.nwin = w.nwin; a.plen = w.plen; a.corr = P;
+        a.spec = (cplx*)(base + w.o_spec); a.nwin = w.nwin; a.plen = w.plen; a.corr = P; a.part = part;
         const size_t lds = fft_lds_bytes(pl.NC);
         hipError_t e = hipSuccess;
         DISPATCH_NC(pl.NC, a.dt, e = launch((spec_kernel<NCC, DTC>), w.nwin, NCC / 8, lds, st, a));
@@ -1644,14 +1671,13 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
         }
         HIPCHK(c, e);
     }
-    hipLaunchKernelGGL(pk_max_partial, dim3((unsigned)w.nb_max), dim3(256), 0, st, (const double*)P, w.plen, part);
     hipLaunchKernelGGL(pk_max_final, dim3(1), dim3(256), 0, st, (const double*)part, (int)w.nb_max, mx);
     hipLaunchKernelGGL(pk_candidates, dim3((unsigned)w.nb_c), dim3(PK_THREADS), 0, st, (const double*)P, w.nz,
                        (const double*)mx, c->cfg.thresh, cnt, (const int64_t*)nullptr, (int64_t*)nullptr);
     hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.nb_c, offs, total);
     hipLaunchKernelGGL(pk_candidates, dim3((unsigned)w.nb_c), dim3(PK_THREADS), 0, st, (const double*)P, w.nz,
                        (const double*)mx, c->cfg.thresh, cnt, (const int64_t*)offs, cand);
-    hipLaunchKernelGGL(pk_nms, dim3(1), dim3(64), 0, st, (const int64_t*)cand, (const int64_t*)total,
+    hipLaunchKernelGGL(pk_nms, dim3(1), dim3(NMS_THREADS), 0, st, (const int64_t*)cand, (const int64_t*)total,
                        (int64_t)c->Lc, w.nz, d_peaks, cap, np);
     HIPCHK(c, hipGetLastError());
     int64_t h[2] = {0, 0};
