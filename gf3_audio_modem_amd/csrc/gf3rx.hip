@@ -687,79 +687,83 @@ __global__ __launch_bounds__(NC / 8, 2) void spec_kernel(OlsArgs a) {
     }
 }
 
+#define OLS_B 4      /* output blocks per workgroup */
 template <int NC>
 __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
-    // Two adjacent output blocks per workgroup: blocks b and b+1 need windows b..b+Q and share Q-1 of
-    // them, so every window spectrum is fetched once for two MACs (the kernel is bound by those reads).
+    // OLS_B adjacent output blocks per workgroup: blocks b .. b+B-1 need windows b .. b+Q+B-2 and share most of
+    // them, so every window spectrum is fetched once for up to B MACs (the kernel is bound by those reads).
     extern __shared__ double2 smem[];
-    constexpr int T = NC / 8;
+    constexpr int T = NC / 8, B = OLS_B;
     cplx* lds = smem;
     const int tid = threadIdx.x;
-    const int64_t b = 2 * (int64_t)blockIdx.x;
+    const int64_t b = B * (int64_t)blockIdx.x;
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
     cplx wb = a.t.twn[tid];
-    cplx acc0[8], acc1[8];
+    cplx acc[B][8];
+    double dc[B], ny[B];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc0[s] = acc1[s] = cmk(0.0, 0.0);
-    double dc0 = 0.0, ny0 = 0.0, dc1 = 0.0, ny1 = 0.0;
-    for (int q = 0; q <= a.Q; ++q) {                 // window b+q feeds block b with H_q and block b+1 with H_{q-1}
-        const cplx* X = a.spec + (b + q) * (int64_t)(NC + 1);
-        const cplx* H0 = a.Hq + (int64_t)(q < a.Q ? q : 0) * (NC + 1);
-        const cplx* H1 = a.Hq + (int64_t)(q > 0 ? q - 1 : 0) * (NC + 1);
-        const bool use0 = q < a.Q, use1 = q > 0 && (b + q) < a.nwin;
+    for (int g = 0; g < B; ++g) {
+        dc[g] = ny[g] = 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[g][s] = cmk(0.0, 0.0);
+    }
+    for (int q = 0; q < a.Q + B - 1; ++q) {          // window b+q feeds block b+g with H_{q-g}
         if (!(b + q < a.nwin)) break;
+        const cplx* X = a.spec + (b + q) * (int64_t)(NC + 1);
+        cplx x[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int k = Spec<NC>::bin(tid, s);
-            const cplx x = X[k];
-            if (use0) acc0[s] = cadd(acc0[s], cmul_conj(x, H0[k]));
-            if (use1) acc1[s] = cadd(acc1[s], cmul_conj(x, H1[k]));
-        }
-        if (tid == 0) {
-            const double x0 = X[0].x, xn = X[NC].x;
-            if (use0) { dc0 += x0 * H0[0].x; ny0 += xn * H0[NC].x; }
-            if (use1) { dc1 += x0 * H1[0].x; ny1 += xn * H1[NC].x; }
+        for (int s = 0; s < 8; ++s) x[s] = X[Spec<NC>::bin(tid, s)];
+        double x0 = 0.0, xn = 0.0;
+        if (tid == 0) { x0 = X[0].x; xn = X[NC].x; }
+#pragma unroll
+        for (int g = 0; g < B; ++g) {
+            const int h = q - g;
+            if (h >= 0 && h < a.Q) {
+                const cplx* H = a.Hq + (int64_t)h * (NC + 1);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc[g][s] = cadd(acc[g][s], cmul_conj(x[s], H[Spec<NC>::bin(tid, s)]));
+                if (tid == 0) { dc[g] += x0 * H[0].x; ny[g] += xn * H[NC].x; }
+            }
         }
     }
     const double inv = 1.0 / (double)NC;
     double mx = -INFINITY;                            // max of the lags this workgroup writes (OFDM.py:359 needs max(P))
-    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+    for (int g = 0; g < B; ++g) {
         const int64_t m0 = (b + g) * (int64_t)a.H;
-        if (m0 >= a.plen) break;
-        lds_barrier();                                // previous output fully read out of LDS
-        // inverse real FFT of the Hermitian spectrum (same construction as corr_kernel)
+        if (m0 < a.plen) {
+            lds_barrier();                                // previous output fully read out of LDS
+            // inverse real FFT of the Hermitian spectrum (same construction as corr_kernel)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = Spec<NC>::bin(tid, 2 * r);
-            const cplx A = g ? acc1[2 * r] : acc0[2 * r];
-            const cplx B = cconj(g ? acc1[2 * r + 1] : acc0[2 * r + 1]);
-            const cplx E = cscale(cadd(A, B), 0.5);
-            const cplx Op = cmul_conj(cscale(csub(A, B), 0.5), Spec<NC>::pair_tw(tid, r, wb));
-            const cplx Zk = cadd(E, mul_posi(Op));
-            const cplx Zm = cadd(cconj(E), mul_posi(cconj(Op)));
-            lds[k] = cconj(Zk);
-            if (Spec<NC>::live(tid, 2 * r + 1)) lds[NC - k] = cconj(Zm);
-        }
-        if (tid == 0) {
-            const double dc = g ? dc1 : dc0, ny = g ? ny1 : ny0;
-            lds[0] = cmk(0.5 * (dc + ny), -0.5 * (dc - ny));
-        }
-        lds_barrier();
-        cplx v[8];
+            for (int r = 0; r < 4; ++r) {
+                const int k = Spec<NC>::bin(tid, 2 * r);
+                const cplx A = acc[g][2 * r];
+                const cplx Bm = cconj(acc[g][2 * r + 1]);
+                const cplx E = cscale(cadd(A, Bm), 0.5);
+                const cplx Op = cmul_conj(cscale(csub(A, Bm), 0.5), Spec<NC>::pair_tw(tid, r, wb));
+                const cplx Zk = cadd(E, mul_posi(Op));
+                const cplx Zm = cadd(cconj(E), mul_posi(cconj(Op)));
+                lds[k] = cconj(Zk);
+                if (Spec<NC>::live(tid, 2 * r + 1)) lds[NC - k] = cconj(Zm);
+            }
+            if (tid == 0) lds[0] = cmk(0.5 * (dc[g] + ny[g]), -0.5 * (dc[g] - ny[g]));
+            lds_barrier();
+            cplx v[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = lds[tid + r * T];
-        lds_barrier();
-        ft.refresh();
-        cplx* yb = fft_core<NC>(v, lds, ft, tid);
-        const int64_t left = a.plen - m0;
-        const int W = left < a.H ? (int)left : a.H;
-        for (int i = tid; 2 * i < W; i += T) {        // y[2n] = Re z / NC, y[2n+1] = -Im z / NC
-            const cplx z = yb[i];
-            const double y0 = z.x * inv, y1 = -z.y * inv;
-            a.corr[m0 + 2 * i] = y0;
-            mx = fmax(mx, y0);
-            if (2 * i + 1 < W) { a.corr[m0 + 2 * i + 1] = y1; mx = fmax(mx, y1); }
+            for (int r = 0; r < 8; ++r) v[r] = lds[tid + r * T];
+            lds_barrier();
+            ft.refresh();
+            cplx* yb = fft_core<NC>(v, lds, ft, tid);
+            const int64_t left = a.plen - m0;
+            const int W = left < a.H ? (int)left : a.H;
+            for (int i = tid; 2 * i < W; i += T) {        // y[2n] = Re z / NC, y[2n+1] = -Im z / NC
+                const cplx z = yb[i];
+                const double y0 = z.x * inv, y1 = -z.y * inv;
+                a.corr[m0 + 2 * i] = y0;
+                mx = fmax(mx, y0);
+                if (2 * i + 1 < W) { a.corr[m0 + 2 * i + 1] = y1; mx = fmax(mx, y1); }
+            }
         }
     }
     mx = block_max(mx, (double*)lds);                 // (starts with a barrier: every wave is done reading yb)
@@ -822,22 +826,29 @@ __global__ void pk_candidates(const double* __restrict__ P, int64_t nz, const do
     int64_t o = offsets[blockIdx.x] + woff + (x - c);
     for (int k = 0; k < PK_ITEMS; ++k) if (flags & (1u << k)) cand[o++] = base + k;
 }
+#define SCAN_PER 16
 __global__ void pk_scan(const int64_t* counts, int64_t n, int64_t* offsets, int64_t* total) {
+    // one workgroup, exclusive scan; each thread owns SCAN_PER consecutive counts per step
     __shared__ int64_t wsum[16];
     __shared__ int64_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int64_t base = 0; base < n; base += blockDim.x) {
-        const int64_t i = base + threadIdx.x;
-        const int64_t c = i < n ? counts[i] : 0;
+    for (int64_t base = 0; base < n; base += (int64_t)blockDim.x * SCAN_PER) {
+        const int64_t i0 = base + (int64_t)threadIdx.x * SCAN_PER;
+        int64_t loc[SCAN_PER];
+        int64_t c = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) { loc[k] = (i0 + k < n) ? counts[i0 + k] : 0; c += loc[k]; }
         int64_t x = c;
         for (int d = 1; d < 64; d <<= 1) { const int64_t y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
         if (lane == 63) wsum[wave] = x;
         __syncthreads();
         int64_t woff = 0, tot = 0;
         for (int w = 0; w < nw; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
-        if (i < n) offsets[i] = carry + woff + (x - c);
+        int64_t o = carry + woff + (x - c);
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) { if (i0 + k < n) offsets[i0 + k] = o; o += loc[k]; }
         __syncthreads();
         if (threadIdx.x == 0) carry += tot;
         __syncthreads();
@@ -1614,7 +1625,7 @@ struct StreamWs { int64_t plen, nz, nb_max, nb_c, nblk, nwin; size_t o_P, o_part
 static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
     StreamWs w;
     w.plen = n + c->Lc - 1; w.nz = w.plen - 2;
-    w.nb_max = ((w.plen + c->stream_plan.Lp - 1) / c->stream_plan.Lp + 1) / 2;      // one partial maximum per ols workgroup
+    w.nb_max = ((w.plen + c->stream_plan.Lp - 1) / c->stream_plan.Lp + OLS_B - 1) / OLS_B;      // one partial maximum per ols workgroup
     w.nb_c = (w.nz + PK_THREADS * PK_ITEMS - 1) / (PK_THREADS * PK_ITEMS);
     if (w.nb_c < 1) w.nb_c = 1;
     size_t o = 0;
@@ -1663,11 +1674,11 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
         HIPCHK(c, e);
         switch (pl.NC) {
 #ifndef GF3_DEV_BUILD
-            case 512:  e = launch(ols_kernel<512>, (w.nblk + 1) / 2, 64, lds, st, a); break;
-            case 1024: e = launch(ols_kernel<1024>, (w.nblk + 1) / 2, 128, lds, st, a); break;
-            case 4096: e = launch(ols_kernel<4096>, (w.nblk + 1) / 2, 512, lds, st, a); break;
+            case 512:  e = launch(ols_kernel<512>, (w.nblk + OLS_B - 1) / OLS_B, 64, lds, st, a); break;
+            case 1024: e = launch(ols_kernel<1024>, (w.nblk + OLS_B - 1) / OLS_B, 128, lds, st, a); break;
+            case 4096: e = launch(ols_kernel<4096>, (w.nblk + OLS_B - 1) / OLS_B, 512, lds, st, a); break;
 #endif
-            default:   e = launch(ols_kernel<2048>, (w.nblk + 1) / 2, 256, lds, st, a); break;
+            default:   e = launch(ols_kernel<2048>, (w.nblk + OLS_B - 1) / OLS_B, 256, lds, st, a); break;
         }
         HIPCHK(c, e);
     }
