@@ -178,7 +178,7 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "traffic_current.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("demod_kernel_bytes_per_launch_at_F", {}).get(str(F))
+            traffic = json.load(open(tfile)).get("demod_kernel_bytes_per_launch_at_F", {}).get(str(Fl))   # same launch size only
         except Exception:
             traffic = None
 
