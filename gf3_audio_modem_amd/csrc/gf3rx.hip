@@ -463,6 +463,27 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         if (l > 0) pack_words(l - 1, false);
         const double fl = ((double)l + 0.5 * (double)P) / denom;          // (l + P/2)/(D+P)
         uint8_t* lab_l = labs + (l & 1) * C;
+        if constexpr (MODE == MODE_QPSK) {
+            // all eight carriers in one straight line: rotate, advance the phasors, take the sign bits; the exact
+            // tie / NaN / Inf rule is one rarely taken branch for the whole group instead of one per carrier
+            cplx ep[8];
+            uint32_t lab[8];
+            bool odd = false;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const cplx g = u[s];
+                ep[s] = cmul_conj(v[s], g);
+                u[s] = cmul(g, gstep[s]);
+                lab[s] = (((uint32_t)__double2hiint(ep[s].y) >> 31) << 1) | ((uint32_t)__double2hiint(ep[s].x) >> 31);
+                odd = odd || __builtin_amdgcn_class(ep[s].x, 0x267) || __builtin_amdgcn_class(ep[s].y, 0x267);
+            }
+            if (odd) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) lab[s] = qpsk_sign_rule(ep[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) if (psl[s] >= 0) lab_l[psl[s]] = (uint8_t)lab[s];
+        } else {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int n = bin_of(s) - 1;
@@ -490,6 +511,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
                     lab_l[ps] = (uint8_t)lab;
                 }
             }
+        }
         }
     }
     GF3_STAMP(4);

@@ -345,6 +345,32 @@ def test_config3_full_size_stream():
     assert 0.0 < res["ber"] < 0.05
 
 
+def test_degenerate_packets_follow_the_reference_tie_rule():
+    """All-zero, NaN and Inf packets: H = 0/NaN, X/H = NaN, and the reference's argmin returns the first
+    constellation point (bits 00) for every carrier.  The sign-rule fast path must fall back to the
+    same answer; lean (QPSK), full and oracle agree."""
+    import warnings
+    g = load("g2_n4096_qpsk")
+    p = params_of(g)
+    n = p.M * p.S + 16
+    rows = np.zeros((4, n))
+    rows[1, :] = np.nan
+    rows[2, :] = np.inf
+    rows[3, 100:200] = 1.0                      # a packet whose pilots are partly zero: exact zeros on some carriers only
+    x = rows.reshape(-1)
+    starts = np.arange(4) * n
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = orc.demod_frames(x, starts, p)["bits"].reshape(4, -1)
+    eng = engine_for(p)
+    xd = torch.from_numpy(x).cuda()
+    lean = eng.unpack_bits(eng.demod_frames(xd, starts, want=())["bits"]).cpu().numpy().reshape(4, -1)
+    full = eng.unpack_bits(eng.demod_frames(xd, starts, want=("eq",))["bits"]).cpu().numpy().reshape(4, -1)
+    assert not ref[:3].any() and not lean[:3].any() and not full[:3].any()
+    assert np.array_equal(full, lean)
+    assert np.array_equal(full[3], ref[3])
+
+
 def test_lean_modes_agree_with_full_on_noisy_qpsk():
     """MODE_QPSK (sign rule, no magnitudes) == MODE_FULL (literal scan on equalised symbols) on noisy data,
     and an all-zero packet (exact ties everywhere) decodes as the reference's argmin does: label 00."""
