@@ -30,17 +30,25 @@ __global__ void chain(double* out, unsigned long long* ticks, double seed) {
     double s = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) s += x[k];
-    out[blockIdx.x * 64 + threadIdx.x] = s;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = t1 - t0; ticks[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
 template <int K, int OP>
 static void run(const char* name, int blocks, int waves_per_block) {
     double* out; unsigned long long* ticks;
-    hipMalloc(&out, sizeof(double) * 64 * 8 * blocks);
+    hipMalloc(&out, sizeof(double) * 64 * 16 * blocks);
     hipMalloc(&ticks, sizeof(unsigned long long) * 2 * blocks);
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((chain<K, OP>), dim3(blocks), dim3(64 * waves_per_block), 0, 0, out, ticks, 1.0);
+    hipLaunchKernelGGL((chain<K, OP>), dim3(blocks), dim3(64 * waves_per_block), 0, 0, out, ticks, 1.0);
     hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((chain<K, OP>), dim3(blocks), dim3(64 * waves_per_block), 0, 0, out, ticks, 1.0);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    printf("    [whole launch %.3f ms: %.1f G lane-instructions/s per SIMD-equivalent of 1024 => %.2f T lane-ops/s]\n", ms,
+           (double)blocks * waves_per_block * 64.0 * NITER * K / (ms * 1e-3) / 1e9 / 1024.0, (double)blocks * waves_per_block * 64.0 * NITER * K / (ms * 1e-3) / 1e12);
     std::vector<unsigned long long> h(2 * blocks);
     hipMemcpy(h.data(), ticks, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost);
     double sum = 0, rsum = 0; for (int i = 0; i < blocks; ++i) { sum += (double)h[2 * i]; rsum += (double)h[2 * i + 1]; }
@@ -66,8 +74,9 @@ int main() {
     run<1, 3>(names[3], 1, 1); run<2, 3>(names[3], 1, 1); run<4, 3>(names[3], 1, 1);
     // two / four waves on one SIMD?  4 waves of one WG land on the 4 SIMDs; 8 waves -> 2 per SIMD
     run<1, 0>(names[0], 1, 4); run<1, 0>(names[0], 1, 8);
-    run<8, 0>(names[0], 1, 4); run<8, 0>(names[0], 1, 8);
+    run<8, 0>(names[0], 1, 4); run<8, 0>(names[0], 1, 8); run<8, 0>(names[0], 1, 16);
+    run<8, 1>(names[1], 1, 4); run<8, 1>(names[1], 1, 8); run<8, 1>(names[1], 1, 16); run<8, 4>(names[4], 1, 4); run<8, 4>(names[4], 1, 16);
     // whole chip busy (DVFS): every CU running 8 waves of the K=8 fma chain
-    run<8, 0>(names[0], 1024, 8); run<8, 1>(names[1], 1024, 8);
+    run<8, 0>(names[0], 1024, 8); run<8, 1>(names[1], 1024, 8); run<8, 0>(names[0], 1024, 4); run<8, 0>(names[0], 2048, 4); run<8, 2>(names[2], 1024, 8);
     return 0;
 }
