@@ -162,6 +162,53 @@ class transmitter(CamG):
             return time_data
         return np.hstack([time_data[:, -self.cp_length:], time_data])
 
+    def build_schmidlcox(self):
+        """OFDM.py:230-238: known symbols on every other carrier.  (K = N/2-1 is odd, so the slice assignment
+        raises ValueError exactly as the reference's does; kept for surface parity -- the standard moved to chirps.)"""
+        symbols = self.map(self.SP(self.known_sequence))
+        p = np.zeros(self.K, dtype=complex)
+        p[::2] = symbols[0, :self.K // 2]
+        return p.reshape(-1, self.K)
+
+    def send_to_stream(self, time_data, sync):
+        """OFDM.py:242-275: frame time-domain symbols (CP already added) into
+        [sync | P known | D data | P known] packets at twice the amplitude, append a final sync, and return the
+        real stream with the reference's three frame masks (each spans one whole stream per packet, as there)."""
+        S = self.ofdm_symbol_size + self.cp_length
+        P, D = self.no_pilots, self.packet_length
+        spec = np.zeros([1, self.ofdm_symbol_size], dtype=complex)
+        known = self.map(self.known_sequence[:self.bits_per_symbol].reshape(-1, self.K, self.mu))
+        spec[0, self.carriers] = known
+        spec[0, -self.carriers] = np.conj(known)
+        known_time = self.add_cp(np.fft.ifft(spec))                       # [1, S]
+        packets = np.asarray(time_data).reshape(-1, D, S)
+        self.no_packets = F = packets.shape[0]
+        pilots = np.tile(known_time, (F, P, 1))
+        sync = np.tile(sync, (F, 1))
+        body = 2 * np.hstack([pilots, packets, pilots])                   # [F, 2P+D, S]
+        tx = np.hstack([sync, body.reshape(F, -1)]).reshape(-1).real
+        tx = np.hstack([tx, sync[0]])
+        n, Lc = tx.shape[0], sync.shape[1]
+        sync_valid, known_valid, payload_valid = np.zeros(n), np.zeros(n), np.zeros(n)
+        sync_valid[:Lc] = 1
+        sync_valid[-Lc:] = 1
+        body_of = lambda f: Lc + S * f + self.cp_length + np.arange(self.ofdm_symbol_size)
+        for f in list(range(P)) + list(range(P + D, 2 * P + D)):
+            known_valid[body_of(f)] = 1
+        for f in range(P, P + D):
+            payload_valid[body_of(f)] = 1
+        return tx, np.tile(sync_valid, F), np.tile(known_valid, F), np.tile(payload_valid, F)
+
+    def graphs(self):
+        """OFDM.py:279-292: plot the constellation with its bit labels."""
+        import matplotlib.pyplot as plt
+        for B, Q in self.mapping_table.items():
+            plt.plot(Q.real, Q.imag, "bo")
+            plt.text(Q.real, Q.imag + 0.1, "".join(str(x) for x in B), ha="center")
+        plt.grid(alpha=0.5); plt.xlim(-1, 1); plt.ylim(-1, 1)
+        plt.title("QPSK Constellation with Gray Mapping")
+        plt.show()
+
     def transmit(self, bits, graph_output=False):
         print("-" * 42 + "\nTRANSMIT\n" + "-" * 42)
         print("OFDM Paramters:")

@@ -293,10 +293,32 @@ def make_schmidlcox(OFDM):
     np.savez_compressed(os.path.join(HERE, "g9_schmidlcox.npz"), r=r, index=idx)
 
 
+def make_send_to_stream(OFDM):
+    """transmitter.send_to_stream (OFDM.py:242-275) and build_schmidlcox (:230-238) on a small geometry:
+    framing of given time-domain symbols into chirp | pilots | data | pilots packets, and the three frame masks."""
+    N, CP, P, D, mu = 1024, 128, 2, 3, 2
+    pts, bt = orc.qpsk_table()
+    K = N // 2 - 1
+    known = orc.load_known_bits(os.path.join(REF, "Handouts", "random_bits.txt"), 4096)
+    tx = reparam(OFDM.transmitter(mode="A1", encoding="None", no_pilots=P, packet_length=D), N, CP, P, D, 1, K, pts, bt, known)
+    rs = np.random.RandomState(10)
+    time_data = rs.randn(2 * D, N + CP) + 1j * rs.randn(2 * D, N + CP)
+    sync = tx.sync_chirp()
+    out, sv, kv, pv = tx.send_to_stream(time_data, sync)
+    try:
+        sc = tx.build_schmidlcox(); sc_err = ""
+    except Exception as e:                      # K is odd for every N: the reference's own slice assignment fails
+        sc = np.zeros((0, K), complex); sc_err = type(e).__name__
+    print("g10_send_to_stream: n=%d masks %d/%d/%d build_schmidlcox -> %s" % (len(out), sv.sum(), kv.sum(), pv.sum(), sc_err or sc.shape))
+    np.savez_compressed(os.path.join(HERE, "g10_send_to_stream.npz"), N=N, CP=CP, P=P, D=D, mu=mu, known_bits=known,
+                        time_data=time_data, tx=out, sync_valid=np.packbits(sv.astype(np.uint8)), known_valid=np.packbits(kv.astype(np.uint8)),
+                        payload_valid=np.packbits(pv.astype(np.uint8)), n_mask=len(sv), schmidlcox=sc, schmidlcox_error=sc_err)
+
+
 def main():
     OFDM = import_reference()
     make_known_bits()
-    which = set(sys.argv[1:]) or {"g1", "g1b", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"}
+    which = set(sys.argv[1:]) or {"g1", "g1b", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"}
     h = np.loadtxt(os.path.join(REF, "Handouts", "gr5channel.csv")).reshape(-1)
     if "g1" in which:
         make_loopback(OFDM, "g1_n1024_qpsk", 1024, 128, 2, 8, 2, 2, seed=1)
@@ -316,6 +338,8 @@ def main():
                       drift=(1.0e-5, 1.0e-4, 22))
     if "g9" in which:
         make_schmidlcox(OFDM)
+    if "g10" in which:
+        make_send_to_stream(OFDM)
     if "g4" in which:
         make_fft(OFDM)
     if "g5" in which:
