@@ -1,0 +1,79 @@
+"""Property tests (hypothesis): noiseless loop-back over random geometries.
+
+CPU: the oracle's transmitter -> the oracle's receiver returns the payload (what the reference's
+`Initial OFDM Test.ipynb:292` asserted for one symbol, here for whole streams).
+GPU: gf3_tx_frames -> gf3_sync_frames -> gf3_demod_frames returns the payload for random (N, CP, P, D, band,
+constellation, sample storage, gaps), and on small cases bits, slopes and sync offsets equal the oracle's on the
+same samples."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import gf3_oracle as orc
+from tests.util import load
+
+KNOWN = load("g6_realrec")["known_bits"]
+
+
+def _params(N, cp_frac, P, D, mu, lo_frac, hi_frac):
+    K = N // 2 - 1
+    lo = 1 + int(lo_frac * (K // 3))
+    hi = max(lo + 8, K - int(hi_frac * (K // 3)))
+    pts, bt = orc.qpsk_table() if mu == 2 else orc.square_qam_table(mu)
+    known = np.tile(KNOWN, -(-K * mu // len(KNOWN)))
+    return orc.RxParams(N=N, CP=max(8, int(cp_frac * N) // 2 * 2), P=P, D=D, lo=lo, hi=hi, const_points=pts, const_bits=bt,
+                        known_bits=known, fit_lo=min(500, K // 3), fit_hi=min(1000, K))
+
+
+geometry = dict(cp_frac=st.sampled_from([1 / 32, 1 / 8, 1 / 4]), P=st.integers(1, 3), D=st.integers(1, 4),
+                mu=st.sampled_from([2, 4, 6]), lo_frac=st.floats(0, 1), hi_frac=st.floats(0, 1), seed=st.integers(0, 2 ** 31 - 1))
+
+
+@settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(N=st.sampled_from([256, 512, 1024]), F=st.integers(1, 3), **geometry)
+def test_oracle_loopback_returns_payload(N, F, cp_frac, P, D, mu, lo_frac, hi_frac, seed):
+    p = _params(N, cp_frac, P, D, mu, lo_frac, hi_frac)
+    rs = np.random.RandomState(seed)
+    payload = rs.randint(0, 2, F * p.D * p.C * p.mu)
+    fill = rs.choice(np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2), size=p.K - p.C)
+    r = orc.tx_stream(payload, fill, p, gaps=rs.randint(0, 100, F), lead=int(rs.randint(0, 50)), tail=int(rs.randint(2, 50)))
+    out = orc.receive(r, p)
+    assert len(out["starts"]) == F
+    assert np.array_equal(out["bits"], payload)
+
+
+@pytest.mark.gpu
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(N=st.sampled_from([1024, 2048, 4096, 8192]), F=st.integers(1, 5),
+       storage=st.sampled_from(["float64", "float32", "int16"]), **geometry)
+def test_gpu_tx_sync_demod_round_trip(N, F, storage, cp_frac, P, D, mu, lo_frac, hi_frac, seed):
+    import torch
+    from gf3_audio_modem_amd import Engine, RxConfig
+    p = _params(N, cp_frac, P, D, mu, lo_frac, hi_frac)
+    dt = getattr(torch, storage)
+    cfg = RxConfig(N=p.N, CP=p.CP, P=p.P, D=p.D, data_bins=p.data_carriers, const_points=p.const_points, const_bits=p.const_bits,
+                   known_bits=p.known_bits, in_dtype=dt, fit_lo=p.fit_lo, fit_hi=p.fit_hi, max_window=256)
+    eng = Engine(cfg)
+    rs = np.random.RandomState(seed)
+    payload = rs.randint(0, 2, F * p.D * p.C * p.mu)
+    packed = orc.pack_bits(payload, p.D * p.C * p.mu)
+    fill = rs.choice(np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2), size=p.K - p.C)
+    filler = np.zeros(p.K, dtype=complex)
+    filler[np.delete(np.arange(1, p.K + 1), p.data_carriers - 1) - 1] = fill
+    gaps = rs.randint(0, 200, F)
+    stride = p.frame_len + 256
+    rows = eng.tx_frames(packed, filler, stride=stride, gaps=gaps, out_dtype=torch.float64)
+    if storage == "int16":                                             # PCM: scale into the int16 range and round
+        rows = torch.round(rows * (20000.0 / float(rows.abs().max()))).to(torch.int16)
+    else:
+        rows = rows.to(dt)
+    starts = eng.sync_frames(rows, F, stride, -8, 248)
+    assert np.array_equal(starts.cpu().numpy(), np.arange(F) * stride + gaps + p.Lc)
+    o = eng.demod_frames(rows, starts, want=("slope",))
+    bits = eng.unpack_bits(o["bits"]).cpu().numpy().reshape(-1)
+    assert np.array_equal(bits, payload)
+    if N <= 2048:                                                      # and everything equals the oracle on these samples
+        x = rows.cpu().numpy().astype(np.float64).reshape(-1)
+        ref = orc.demod_frames(x, starts.cpu().numpy(), p)
+        assert np.array_equal(bits, ref["bits"].reshape(-1))
+        np.testing.assert_allclose(o["slope"].cpu().numpy(), ref["slope"], rtol=0, atol=1e-10)
