@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--chunks", type=int, default=4, help="N>1: pieces the batch is cut into to overlap the all-gather")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rehearse-chunked", action="store_true",
+                    help="N=1 only: run the N>1 code path (chunked launches, per-chunk all-gather on a side stream) "
+                         "through a one-rank RCCL group; a rehearsal of the multi-GPU path, not the headline number")
     args = ap.parse_args()
 
     from gf3_audio_modem_amd import dist as gd
@@ -105,21 +108,28 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    multi = world > 1
+    if args.rehearse_chunked and world == 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        multi = True
 
     eng, cfg, big, payload, gaps = build_workload(args, rank)
     F = args.frames
     n_samples = F * args.stride
     bits = torch.empty((F, eng.bytes_per_frame), dtype=torch.uint8, device=dev)
-    gathered = torch.empty((F * world, eng.bytes_per_frame), dtype=torch.uint8, device=dev) if world > 1 else None
-    chunks = args.chunks if (world > 1 and F % args.chunks == 0) else 1
+    gathered = torch.empty((F * world, eng.bytes_per_frame), dtype=torch.uint8, device=dev) if multi else None
+    chunks = args.chunks if (multi and F % args.chunks == 0) else 1
     Fc = F // chunks
-    og = gd.OverlappedGather(gathered, F, chunks) if world > 1 else None
+    og = gd.OverlappedGather(gathered, F, chunks) if multi else None
     starts_all = torch.empty((F,), dtype=torch.int64, device=dev)
 
     def step(ev=None):
         """N=1: one launch of each kernel over the whole batch.  N>1: per chunk, sync + demod on
         this rank's rows, then that chunk's packed bits are all-gathered on a side stream."""
-        if world == 1:
+        if not multi:
             if ev: ev[0].record()
             starts = eng.sync_frames(big, F, args.stride, WIN_LO, WIN_LO + args.window)
             if ev: ev[1].record()
@@ -159,7 +169,7 @@ def main():
     exp_starts = torch.arange(F, device=dev, dtype=torch.int64) * args.stride + gaps + cfg.chirp_length
     sync_ok = bool(torch.equal(starts, exp_starts))
     gather_ok = None
-    if world > 1:       # every rank must hold every rank's bits, in the block-cyclic global order
+    if multi:           # every rank must hold every rank's bits, in the block-cyclic global order
         mine = gd.cyclic_frame_index(rank, world, F, chunks).to(dev)
         gather_ok = bool(torch.equal(gathered[mine], bits))
         flag = torch.tensor([1.0 if gather_ok else 0.0], dtype=torch.float64, device=dev)
@@ -170,7 +180,7 @@ def main():
     t_sync = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])) * 1e-3
     t_demod = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) * 1e-3
     b_in = 4
-    Fl = F if world == 1 else Fc                 # frames per timed launch
+    Fl = Fc if multi else F                      # frames per timed launch
     bytes_demod = Fl * (b_in * cfg.M * cfg.N + eng.bytes_per_frame)                     # 200 700 B/frame
     bytes_sync = Fl * (b_in * (cfg.chirp_length + args.window - 1) + 8)
     ach = bytes_demod / t_demod / 1e9
@@ -193,7 +203,7 @@ def main():
                                    "windowed chirp sync + LS pilot equalisation + hard demap",
                        "frames_per_gpu": F, "samples_per_frame": args.stride, "sample_storage": "f32",
                        "sync_window_lags": args.window, "parallelism": f"frames sharded over {world} GPU(s), "
-                       f"packed bits all-gathered in {chunks} chunk(s) under compute" if world > 1 else "single GPU"},
+                       f"packed bits all-gathered in {chunks} chunk(s) under compute" if multi else "single GPU"},
             "ber": bit_errors / (F * cfg.bits_per_frame), "bit_errors": bit_errors, "frames_checked": F, "sync_exact": sync_ok,
             "gather_exact": gather_ok,
             "roofline": {"kernel": "demod_kernel<2048,f32,MODE_QPSK>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
@@ -203,11 +213,11 @@ def main():
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_sync / t_sync / 1e9 / HBM_PEAK_GBS,
                               "algorithmic_bytes_per_launch": bytes_sync, "avg_launch_ms": t_sync * 1e3},
         }
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not multi and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg, big, payload, args.window, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -65,11 +65,12 @@ class OverlappedGather:
         self.out, self.F, self.chunks = out, F_local, chunks
         self.Fc = F_local // chunks
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.active = dist.is_initialized()           # a one-rank group still runs the collective (rehearsal)
         self.side = torch.cuda.Stream() if out.is_cuda else None
         self.works = []
 
     def chunk_done(self, c: int, local_bits_chunk: torch.Tensor):
-        if self.world == 1:
+        if not self.active:
             return
         dst = self.out[c * self.world * self.Fc: (c + 1) * self.world * self.Fc]
         if self.side is None:
