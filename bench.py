@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--frames", type=int, default=65536, help="frames per GPU")
     ap.add_argument("--stride", type=int, default=78720)
     ap.add_argument("--window", type=int, default=320)
-    ap.add_argument("--chunks", type=int, default=4, help="N>1: pieces the batch is cut into to overlap the all-gather")
+    ap.add_argument("--chunks", type=int, default=8, help="N>1: pieces the batch is cut into to overlap the all-gather")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--rehearse-chunked", action="store_true",
