@@ -208,7 +208,9 @@ def main():
             "gather_exact": gather_ok,
             "roofline": {"kernel": "demod_kernel<2048,f32,MODE_QPSK>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": bytes_demod, "avg_launch_ms": t_demod * 1e3},
+                         "algorithmic_bytes_per_launch": bytes_demod, "avg_launch_ms": t_demod * 1e3,
+                         "limiter": "package power: 1.38 kW of the 1.4 kW cap while this runs (rocm-smi), energy dominated "
+                                    "by the fp64 operation count of the transforms (DESIGN.md section 8)"},
             "roofline_sync": {"kernel": "corr_kernel<1024,f32> (15 x 2048-point transforms per packet)", "bound": "hbm", "achieved": bytes_sync / t_sync / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_sync / t_sync / 1e9 / HBM_PEAK_GBS,
                               "algorithmic_bytes_per_launch": bytes_sync, "avg_launch_ms": t_sync * 1e3},
