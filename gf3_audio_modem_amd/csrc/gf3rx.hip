@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         if (i + 1 < Msym) fetch(i + 1);
         ft.refresh();
         asm volatile("" : "+v"(wb.x), "+v"(wb.y));
-        rfft_regs<NC, DemodOcc<NC, MODE>::PP>(v, lds, ft, wb, tq, z0, i & 1);
+        rfft_regs<NC, DemodOcc<NC, MODE>::PP, true>(v, lds, ft, wb, tq, z0, i & 1);
     };
     auto load_spectra = [&](const cplx* sp) {         // SPECTRA mode: slots straight from memory
 #pragma unroll
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
             for (int r = 0; r < 8; ++r) v[r] = sum[r];
             ft.refresh();
             asm volatile("" : "+v"(wb.x), "+v"(wb.y));
-            rfft_regs<NC, DemodOcc<NC, MODE>::PP>(v, lds, ft, wb, tq, z0, side);
+            rfft_regs<NC, DemodOcc<NC, MODE>::PP, true>(v, lds, ft, wb, tq, z0, side);
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) { if (side) He[s2] = v[s2]; else Hs[s2] = v[s2]; }
         }
@@ -317,7 +317,11 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     cplx* hel = hsl + L;                              // [L] same for He
     cplx u[8];
     double a0[8], da[8];
-    const double invP = 1.0 / (double)P;
+    // The transforms of this kernel leave 2 X in the slots (rfft_regs<.., TWICE>): XS is that factor (1 when the
+    // spectra come from memory).  It is divided out of the pilots here and carried by the magnitudes a0, da, so the
+    // channel estimates are true-scale and X/Hest is unchanged -- bit for bit, powers of two being exact.
+    constexpr double XS = SPECTRA ? 1.0 : 2.0;
+    const double invP = (1.0 / (double)P) / XS;
     // (a) straight-line over the 8 slots (independent chains overlap): H = mean/known, unit phasor, magnitudes
     cplx ik[8];                                       // 1/known (L2 latency covered by the other resident workgroup)
 #pragma unroll
@@ -330,8 +334,9 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         const double ia = rsq_nr(m2);                                 // 1/|Hs|
         if constexpr (MODE != MODE_QPSK) {
             const double e2 = He[s].x * He[s].x + He[s].y * He[s].y;
-            a0[s] = m2 * ia;                                          // |Hs|
-            da[s] = e2 * rsq_nr(e2) - a0[s];                          // |He| - |Hs|
+            const double ah = m2 * ia;                                // |Hs|
+            a0[s] = XS * ah;
+            da[s] = XS * (e2 * rsq_nr(e2) - ah);                      // XS (|He| - |Hs|)
         }
         u[s] = cmk(Hs[s].x * ia, Hs[s].y * ia);
     }
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
                 const cplx e = cscale(ep, rcp_nr(mag));
                 if constexpr (FULL) {
                     if (live_of(s)) {
-                        if (a.Hest) a.Hest[((int64_t)f * D + l) * K + n] = cscale(g, mag);
+                        if (a.Hest) a.Hest[((int64_t)f * D + l) * K + n] = cscale(g, mag * (1.0 / XS));
                         if (a.eq_all) a.eq_all[((int64_t)f * D + l) * K + n] = e;
                     }
                     if (ps >= 0 && a.eq) a.eq[((int64_t)f * D + l) * C + ps] = e;

@@ -228,11 +228,15 @@ template <int NC> struct Spec {
     }
 };
 
-// packed-real split of one mirrored pair: A = Z[k], Bm = Z[NC-k], w = exp(-2 pi i k / N)
+// packed-real split of one mirrored pair: A = Z[k], Bm = Z[NC-k], w = exp(-2 pi i k / N).
+// TWICE = true returns 2 X[k], 2 X[N/2-k]: the two halvings are dropped (four multiplies per pair); callers whose
+// results are ratios or signs of spectra fold the factor of two -- exact in binary -- into a constant they apply anyway.
+template <bool TWICE = false>
 GF3_DEV void real_split(cplx A, cplx Bm, cplx w, cplx& Xk, cplx& Xm) {
     const cplx B = cconj(Bm);
-    const cplx E = cscale(cadd(A, B), 0.5);
-    const cplx O = cmul(mul_negi(cscale(csub(A, B), 0.5)), w);
+    const cplx E = TWICE ? cadd(A, B) : cscale(cadd(A, B), 0.5);
+    const cplx D = TWICE ? csub(A, B) : cscale(csub(A, B), 0.5);
+    const cplx O = cmul(mul_negi(D), w);
     Xk = cadd(E, O);
     Xm = cconj(csub(E, O));
 }
@@ -313,10 +317,11 @@ template <int NC> GF3_DEV void FftTw<NC>::init(int tid, const cplx* __restrict__
 
 // Real FFT of one packed symbol with the spectrum left in registers in Spec<NC> slot order.
 // In: v[r] = z[t + r*NC/8] (t = threadIdx.x); wb = exp(-2 pi i t / (2NC)); z0 (thread 0) = Z[0].
+// TWICE: slots hold 2 X (see real_split); z0 is not affected.
 // `flip` must alternate between consecutive calls in a workgroup (ping-pong hazard: the last
 // pass of call i reads buffer A_i with no barrier after it; call i+1 starts by storing into the
 // other buffer, which every wave finished reading before call i's final barrier).
-template <int NC, bool PP = FftGeom<NC>::PINGPONG>
+template <int NC, bool PP = FftGeom<NC>::PINGPONG, bool TWICE = false>
 GF3_DEV void rfft_regs(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, cplx wb, int t, cplx& z0, int flip) {
     if constexpr (Spec<NC>::FUSED) {
         constexpr int Q = NC / 4;
@@ -337,7 +342,7 @@ GF3_DEV void rfft_regs(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, cplx wb, in
         const cplx A[4] = {sel(a[2], a[0]), a[1], sel(b[0], a[2]), sel(b[1], a[3])};
         const cplx Bm[4] = {sel(a[2], b[3]), sel(a[3], b[2]), sel(b[3], b[1]), sel(b[2], b[0])};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) real_split(A[r], Bm[r], Spec<NC>::pair_tw(t, r, wb), v[2 * r], v[2 * r + 1]);
+        for (int r = 0; r < 4; ++r) real_split<TWICE>(A[r], Bm[r], Spec<NC>::pair_tw(t, r, wb), v[2 * r], v[2 * r + 1]);
     } else {
         const cplx* Z = fft_passes<NC, true, PP>(v, lds, ft, t, 0);
         z0 = Z[0];
@@ -345,7 +350,7 @@ GF3_DEV void rfft_regs(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, cplx wb, in
         for (int r = 0; r < 4; ++r) {
             const int k = Spec<NC>::bin(t, 2 * r);
             const cplx A = Z[k], Bm = Z[NC - k];
-            real_split(A, Bm, Spec<NC>::pair_tw(t, r, wb), v[2 * r], v[2 * r + 1]);
+            real_split<TWICE>(A, Bm, Spec<NC>::pair_tw(t, r, wb), v[2 * r], v[2 * r + 1]);
         }
     }
 }
