@@ -600,7 +600,7 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         if (tid == 0) { h0 = Hq[0].x; hN = Hq[NC].x; }
         ft.refresh();
         asm volatile("" : "+v"(wb.x), "+v"(wb.y));
-        rfft_regs<NC, PP>(v, lds, ft, wb, tq, z0, q & 1);
+        rfft_regs<NC, PP, true>(v, lds, ft, wb, tq, z0, q & 1);       // slots hold 2 X: undone by `inv` below
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[s] = cadd(acc[s], cmul_conj(v[s], hq[s]));
         if (tid == 0) {
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         }
     }
     if (tid == 0) {
-        const double E = 0.5 * (accDC + accNy), Op = 0.5 * (accDC - accNy);
+        const double E = accDC + accNy, Op = accDC - accNy;                 // 2 x (E, Op): same scale as the slots
         lds[0] = cmk(E, -Op);                                               // conj(E + i Op)
     }
     lds_barrier();
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
     lds_barrier();                                   // everyone holds its inputs: both buffers are free
     cplx* yb = fft_core<NC, PP>(v, lds, ft, launder(tid));
     // z = conj(FFT(conj Z))/NC ; y[2n] = Re z, y[2n+1] = Im z  -> in place as doubles
-    const double inv = 1.0 / (double)NC;
+    const double inv = 0.5 / (double)NC;             // 1/NC of the inverse transform and the 2 of the forward ones (exact)
     for (int i = tid; i < NC; i += T) { const cplx z = yb[i]; yb[i] = cmk(z.x * inv, -z.y * inv); }
     lds_barrier();
     const double* y = (const double*)yb;
