@@ -337,12 +337,19 @@ GF3_DEV void rfft_regs(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, cplx wb, in
         bfly4(a);
         bfly4(b);
         z0 = a[0];
-        const bool t0 = (t == 0);
-        auto sel = [&](cplx x, cplx y) { return cmk(t0 ? x.x : y.x, t0 ? x.y : y.y); };
-        const cplx A[4] = {sel(a[2], a[0]), a[1], sel(b[0], a[2]), sel(b[1], a[3])};
-        const cplx Bm[4] = {sel(a[2], b[3]), sel(a[3], b[2]), sel(b[3], b[1]), sel(b[2], b[0])};
+        // Only thread 0 pairs its outputs differently (its two butterflies mirror onto themselves).  The ~40 selects
+        // that costs are confined to its wave by a scalar branch; the other waves run the plain pairing.
+        if (__builtin_amdgcn_readfirstlane(t) < 64) {
+            const bool t0 = (t == 0);
+            auto sel = [&](cplx x, cplx y) { return cmk(t0 ? x.x : y.x, t0 ? x.y : y.y); };
+            const cplx A[4] = {sel(a[2], a[0]), a[1], sel(b[0], a[2]), sel(b[1], a[3])};
+            const cplx Bm[4] = {sel(a[2], b[3]), sel(a[3], b[2]), sel(b[3], b[1]), sel(b[2], b[0])};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) real_split<TWICE>(A[r], Bm[r], Spec<NC>::pair_tw(t, r, wb), v[2 * r], v[2 * r + 1]);
+            for (int r = 0; r < 4; ++r) real_split<TWICE>(A[r], Bm[r], Spec<NC>::pair_tw(t, r, wb), v[2 * r], v[2 * r + 1]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) real_split<TWICE>(a[r], b[3 - r], Spec<NC>::pair_tw(1, r, wb), v[2 * r], v[2 * r + 1]);
+        }
     } else {
         const cplx* Z = fft_passes<NC, true, PP>(v, lds, ft, t, 0);
         z0 = Z[0];
