@@ -1552,7 +1552,6 @@ __global__ __launch_bounds__(1024) void schmidl_cox_kernel(ScArgs a) {
     __shared__ double wsum[16];
     __shared__ double bval[16];
     __shared__ long long bidx[16];
-    __shared__ double carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int ITEMS = 4;
     double best = 0.0;                 // |P[0]| = 0 at index 0
