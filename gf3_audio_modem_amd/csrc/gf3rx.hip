@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void rfft_kernel(RfftArgs a) 
         v[r] = raw.get();
     }
     cplx z0;
-    rfft_regs<NC>(v, smem, ft, wb, tid, z0, 0);
+    rfft_regs<NC, false>(v, smem, ft, wb, tid, z0, 0);      // single in-place buffer: twice the resident workgroups
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2)
         if (Spec<NC>::live(tid, s2)) out[Spec<NC>::bin(tid, s2)] = v[s2];
@@ -1184,11 +1184,11 @@ static hipError_t run_rfft_nc(int NCv, FftTables t, const void* d_in, int64_t n_
     hipError_t e = hipSuccess;
 #ifdef GF3_DEV_BUILD
     if (NCv == 1024) {
-        if (dt == DT_F64) return launch((rfft_kernel<1024, DT_F64>), n_sym, 128, fft_lds_bytes(1024), st, a);
-        return launch((rfft_kernel<1024, DT_F32>), n_sym, 128, fft_lds_bytes(1024), st, a);
+        if (dt == DT_F64) return launch((rfft_kernel<1024, DT_F64>), n_sym, 128, (size_t)(1024 + 128) * sizeof(cplx), st, a);
+        return launch((rfft_kernel<1024, DT_F32>), n_sym, 128, (size_t)(1024 + 128) * sizeof(cplx), st, a);
     }
 #endif
-    DISPATCH_NC(NCv, dt, e = launch((rfft_kernel<NCC, DTC>), n_sym, NCC / 8, fft_lds_bytes(NCC), st, a));
+    DISPATCH_NC(NCv, dt, e = launch((rfft_kernel<NCC, DTC>), n_sym, NCC / 8, (size_t)(NCC + NCC / 8) * sizeof(cplx), st, a));
     return e;
 }
 static hipError_t run_rfft(const gf3_ctx* c, const void* d_in, int64_t n_in, int dt, const int64_t* d_off,
