@@ -987,6 +987,60 @@ __global__ void soft_demap_kernel(DemapArgs a) {
     }
 }
 
+// Separable tables (grid constellations with per-axis bit labels): a bit owned by one axis sees the other axis'
+// term cancel in the difference, so its LLR needs that axis' <= 8 squared distances only.  Everything that steers
+// the reduction (which axis owns bit b, which levels carry a 1 there, how many levels exist) is wave-uniform and
+// lives in scalar registers; the loops are fully unrolled over MU bits x 8 levels, each step one scalar bit test
+// around one v_min_f64.
+template <int MU>
+__global__ __launch_bounds__(256) void soft_demap_sep_kernel(DemapArgs a) {
+    int ones[MU];                                    // bit b: mask of the owning axis' levels whose label has a 1 there
+    bool onI[MU];
+#pragma unroll
+    for (int b = 0; b < MU; ++b) {
+        onI[b] = (a.sep.maskI >> (MU - 1 - b)) & 1;
+        ones[b] = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ones[b] |= (((onI[b] ? a.sep.labI[k] : a.sep.labQ[k]) >> (MU - 1 - b)) & 1) << k;
+    }
+    const int nI = a.sep.nI, nQ = a.sep.nQ;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cplx e = a.sym[i];
+        double dI[8], dQ[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double tI = e.x - a.sep.lvI[k], tQ = e.y - a.sep.lvQ[k];
+            dI[k] = tI * tI; dQ[k] = tQ * tQ;
+        }
+        float out[MU];
+#pragma unroll
+        for (int b = 0; b < MU; ++b) {
+            double m0 = INFINITY, m1 = INFINITY;
+            // (opaque per symbol: otherwise the 8 MU level tests are hoisted out of the symbol loop as 8 MU SGPR
+            //  pairs, which spill to VGPR lanes and come back through v_readlane on every use)
+            asm volatile("" : "+s"(ones[b]));
+            if (onI[b]) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k < nI) { if ((ones[b] >> k) & 1) m1 = fmin(m1, dI[k]); else m0 = fmin(m0, dI[k]); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k < nQ) { if ((ones[b] >> k) & 1) m1 = fmin(m1, dQ[k]); else m0 = fmin(m0, dQ[k]); }
+            }
+            out[b] = (float)((m1 - m0) * a.inv_nv);
+        }
+        if constexpr (MU % 4 == 0) {                  // 16-byte aligned rows
+#pragma unroll
+            for (int b = 0; b < MU; b += 4) *(float4*)(a.llr + i * MU + b) = make_float4(out[b], out[b + 1], out[b + 2], out[b + 3]);
+        } else if constexpr (MU % 2 == 0) {           // 8-byte aligned rows
+#pragma unroll
+            for (int b = 0; b < MU; b += 2) *(float2*)(a.llr + i * MU + b) = make_float2(out[b], out[b + 1]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < MU; ++b) a.llr[i * MU + b] = out[b];
+        }
+    }
+}
+
 // ============================================================================
 // transmit-side synthesiser: one packet per workgroup
 // transmitter.map / build_OFDM_symbol / ifft / add_cp / send_to_stream (OFDM.py:196-259)
@@ -1731,7 +1785,18 @@ static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, ui
     if (grid > 256 * 16) grid = 256 * 16;
     if (grid < 1) return GF3_OK;
     if (bits) hipLaunchKernelGGL(demap_hard_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(soft_demap_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    else if (c->sep.nI > 0) {
+        switch (c->cfg.mu) {
+            case 1: hipLaunchKernelGGL(soft_demap_sep_kernel<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+            case 2: hipLaunchKernelGGL(soft_demap_sep_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+            case 3: hipLaunchKernelGGL(soft_demap_sep_kernel<3>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+            case 4: hipLaunchKernelGGL(soft_demap_sep_kernel<4>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+            case 5: hipLaunchKernelGGL(soft_demap_sep_kernel<5>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+            case 6: hipLaunchKernelGGL(soft_demap_sep_kernel<6>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+            case 7: hipLaunchKernelGGL(soft_demap_sep_kernel<7>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+            default: hipLaunchKernelGGL(soft_demap_sep_kernel<8>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+        }
+    } else hipLaunchKernelGGL(soft_demap_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     HIPCHK(c, hipGetLastError());
     return GF3_OK;
 }
