@@ -153,9 +153,15 @@ GF3_DEV uint32_t qpsk_sign_rule(cplx e) {
 GF3_DEV int sep_axis(double x, const double* lv, int n, bool& clear) {
     double d0 = (x - lv[0]) * (x - lv[0]), d1 = INFINITY;
     int best = 0;
-    for (int i = 1; i < n; ++i) {
-        const double d = (x - lv[i]) * (x - lv[i]);
-        if (d < d0) { d1 = d0; d0 = d; best = i; } else if (d < d1) d1 = d;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {                   // <= 8 levels per axis (M <= 64); n is wave-uniform
+        if (i < n) {
+            const double d = (x - lv[i]) * (x - lv[i]);
+            const bool lt = d < d0;
+            d1 = lt ? d0 : fmin(d1, d);             // runner-up (fmin: a NaN d leaves it, as `d < d1` did)
+            best = lt ? i : best;
+            d0 = lt ? d : d0;
+        }
     }
     clear = (d1 - d0) > 1e-9 * (d1 + d0);       // false also for NaN / Inf inputs
     return best;
