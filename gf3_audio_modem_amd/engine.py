@@ -233,10 +233,16 @@ class Engine:
             _ptr(o["slope"]), _ptr(o.get("Hest")), _ptr(o["bits"]), self._stream()))
         return o
 
-    def sync_frames(self, x, F, stride, win_lo, win_hi, want_peak=False):
-        """Batched windowed chirp sync: first-pilot sample index per frame (int64, -1 = none)."""
+    def sync_frames(self, x, F, stride, win_lo, win_hi, want_peak=False, out_starts=None):
+        """Batched windowed chirp sync: first-pilot sample index per frame (int64, -1 = none).
+        out_starts: optional preallocated int64 [F] device tensor to write into."""
         x = self._samples(x)
-        starts = self._new((F,), torch.int64)
+        if out_starts is not None:
+            if out_starts.dtype != torch.int64 or out_starts.numel() != F or not out_starts.is_contiguous():
+                raise ValueError("out_starts must be a contiguous int64 tensor of F elements")
+            starts = out_starts
+        else:
+            starts = self._new((F,), torch.int64)
         peak = self._new((F,), torch.float64) if want_peak else None
         self._check(self.lib.gf3_sync_frames(self._h, _ptr(x), x.numel(), F, stride, win_lo, win_hi,
                                              _ptr(starts), _ptr(peak), self._stream()))
