@@ -889,10 +889,13 @@ __global__ void pk_scan(const int64_t* counts, int64_t n, int64_t* offsets, int6
     if (threadIdx.x == 0) total[0] = carry;
 }
 // sequential suppression (OFDM.py:364-370) over the sorted candidate list: an accepted candidate i suppresses
-// everything up to i+Lc, so the next survivor is the first candidate >= i+Lc+1.  One workgroup walks the list in
-// chunks staged in LDS: every thread finds the successor of its candidates by binary search (parallel), then one
-// thread follows the successor chain (one LDS round trip per accepted peak instead of two dependent global loads).
-#define NMS_CHUNK 4096
+// everything up to i+Lc, so the next survivor is succ(k) = the first candidate >= i+Lc+1, and the accepted set is
+// the orbit of the first candidate under succ.  One workgroup walks the list in chunks staged in LDS:
+//   1. every thread finds succ of its candidates by binary search (parallel);
+//   2. five doubling rounds give succ^2, succ^4 ... succ^32;
+//   3. one wave emits 64 accepted peaks per step: lane l composes succ^l from the bits of l (six dependent LDS
+//      reads for all lanes at once, instead of one dependent read per accepted peak).
+#define NMS_CHUNK 2048
 #define NMS_THREADS 1024
 GF3_DEV int nms_lower_bound(const int64_t* v, int n, int64_t want) {     // first k in [0, n] with v[k] >= want
     int lo = 0, hi = n;
@@ -902,8 +905,8 @@ GF3_DEV int nms_lower_bound(const int64_t* v, int n, int64_t want) {     // firs
 __global__ __launch_bounds__(NMS_THREADS) void pk_nms(const int64_t* cand, const int64_t* totalp, int64_t Lc, int64_t nz,
                                                       int64_t* peaks, int64_t cap, int64_t* npeaks) {
     __shared__ int64_t sv[NMS_CHUNK];
-    __shared__ int succ[NMS_CHUNK];
-    __shared__ int64_t st[3];                                            // np, status, want (thread 0 -> all)
+    __shared__ unsigned short J[6][NMS_CHUNK + 1];                       // J[t][k] = succ^(2^t)(k); index m = "past the chunk"
+    __shared__ int64_t st[3];                                            // np, status, want (wave 0 -> all)
     const int64_t total = totalp[0];
     if (threadIdx.x == 0) { st[0] = 0; st[1] = 0; st[2] = INT64_MIN; }
     __syncthreads();
@@ -912,20 +915,35 @@ __global__ __launch_bounds__(NMS_THREADS) void pk_nms(const int64_t* cand, const
         for (int k = threadIdx.x; k < m; k += NMS_THREADS) sv[k] = cand[c0 + k];
         __syncthreads();
         if (st[1] == 1) break;                                           // wiped: nothing can be accepted any more
-        for (int k = threadIdx.x; k < m; k += NMS_THREADS) succ[k] = nms_lower_bound(sv, m, sv[k] + Lc + 1);
+        for (int k = threadIdx.x; k <= m; k += NMS_THREADS)
+            J[0][k] = (unsigned short)(k < m ? nms_lower_bound(sv, m, sv[k] + Lc + 1) : m);
         __syncthreads();
-        if (threadIdx.x == 0) {
+        for (int t = 1; t < 6; ++t) {
+            for (int k = threadIdx.x; k <= m; k += NMS_THREADS) J[t][k] = J[t - 1][J[t - 1][k]];
+            __syncthreads();
+        }
+        if (threadIdx.x < 64) {                                          // wave 0
+            const int lane = threadIdx.x;
             int64_t np = st[0], status = st[1], want = st[2];
-            int k = nms_lower_bound(sv, m, want);
-            while (k < m) {
-                const int64_t i = sv[k];
-                if (i + Lc >= nz) { np = 0; status = 1; break; }         // the except-branch wipes everything
-                if (np < cap) peaks[np] = i; else status = 2;
-                ++np;
-                want = i + Lc + 1;
-                k = succ[k];
+            int k0 = nms_lower_bound(sv, m, want);                       // wave-uniform
+            while (k0 < m) {
+                int k = k0;                                              // lane l: succ^l(k0)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) if ((lane >> t) & 1) k = J[t][k];
+                const bool live = k < m;
+                const int64_t i = live ? sv[k] : 0;
+                const unsigned long long wipe = __ballot(live && (i + Lc >= nz));
+                if (wipe) { np = 0; status = 1; break; }                 // the except-branch wipes everything
+                if (live) { if (np + lane < cap) peaks[np + lane] = i; }
+                const unsigned long long lv = __ballot(live);
+                const int cnt = __popcll(lv);                            // live lanes are a prefix: succ is increasing
+                if (np + cnt > cap) status = 2;
+                np += cnt;
+                const int klast = __shfl(k, cnt - 1, 64);
+                want = __shfl(i, cnt - 1, 64) + Lc + 1;
+                k0 = J[0][klast];
             }
-            st[0] = np; st[1] = status; st[2] = want;
+            if (lane == 0) { st[0] = np; st[1] = status; st[2] = want; }
         }
         __syncthreads();
     }
