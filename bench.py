@@ -243,10 +243,21 @@ def main():
     sync_ok = bool(torch.equal(starts, exp_starts))
     gather_ok = None
     if multi:           # every rank must hold every rank's bits, in the block-cyclic global order
+        import torch.distributed as tdist
         mine = gd.cyclic_frame_index(rank, world, F, chunks).to(dev)
         gather_ok = bool(torch.equal(gathered[mine], bits))
+        # ... and this rank's copy of every OTHER rank's rows matches what that rank decoded (a checksum of each
+        # rank's rows, weighted by row number, is exchanged and recomputed on the local copy)
+        w = (torch.arange(F, device=dev, dtype=torch.int64) % 65521 + 1)[:, None]
+        def checksum(rows):
+            return (rows.to(torch.int64) * w).sum()
+        sums = torch.zeros(world, dtype=torch.int64, device=dev)
+        sums[rank] = checksum(bits)
+        tdist.all_reduce(sums, op=tdist.ReduceOp.SUM)
+        for r in range(world):
+            idx = gd.cyclic_frame_index(r, world, F, chunks).to(dev)
+            gather_ok = gather_ok and bool(checksum(gathered[idx]) == sums[r])
         flag = torch.tensor([1.0 if gather_ok else 0.0], dtype=torch.float64, device=dev)
-        import torch.distributed as tdist
         tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
         gather_ok = bool(flag.item() == 1.0)
 
