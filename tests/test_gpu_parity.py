@@ -566,3 +566,27 @@ def test_integration_md_ctypes_stub_runs(capsys):
     capsys.readouterr()
     assert np.array_equal(np.asarray(bits), np.asarray(ref_bits))
     assert np.abs(Hs0 - ref_Hs0).max() <= 1e-12 and np.abs(He0 - ref_He0).max() <= 1e-12
+
+
+def test_bench_json_contract(capsys, monkeypatch):
+    """bench.py's one JSON line (small batch, in-process): the contract keys, BER 0, exact sync, a roofline object
+    whose fraction is achieved/peak, and no CPU leg when --no-cpu is given."""
+    import importlib.util, json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gf3_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--frames", "1024", "--steps", "2", "--warmup", "1", "--no-cpu"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    bench.main()
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "samples/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["ber"] == 0.0 and d["sync_exact"] is True and "cpu_baseline" not in d
+    assert abs(d["value"] - 1024 * 78720 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
