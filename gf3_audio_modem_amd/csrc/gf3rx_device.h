@@ -105,12 +105,15 @@ GF3_DEV void bfly8(cplx* v) {
     const cplx a6 = cadd(v[3], v[7]), a7 = mul_negi(csub(v[3], v[7]));
     const cplx b0 = cadd(a0, a2), b1 = cadd(a1, a3), b2 = csub(a0, a2), b3 = csub(a1, a3);
     const cplx b4 = cadd(a4, a6), o1 = cadd(a5, a7), b6 = mul_negi(csub(a4, a6)), o3 = csub(a5, a7);
-    const cplx b5 = cmk((o1.x + o1.y) * GF3_SQRT1_2, (o1.y - o1.x) * GF3_SQRT1_2);    // * (1-i)/sqrt2
-    const cplx b7 = cmk((o3.y - o3.x) * GF3_SQRT1_2, -(o3.x + o3.y) * GF3_SQRT1_2);   // * (-1-i)/sqrt2
+    // b5 = o1 (1-i)/sqrt2 and b7 = o3 (-1-i)/sqrt2 are never formed: the 1/sqrt2 rides on the fma of b +- b5, b +- b7
+    const double p1 = o1.x + o1.y, m1 = o1.y - o1.x;            // b5 = (p1, m1) / sqrt2
+    const double m3 = o3.y - o3.x, p3 = o3.x + o3.y;            // b7 = (m3, -p3) / sqrt2
     v[0] = cadd(b0, b4); v[4] = csub(b0, b4);
-    v[1] = cadd(b1, b5); v[5] = csub(b1, b5);
+    v[1] = cmk(fma(GF3_SQRT1_2, p1, b1.x), fma(GF3_SQRT1_2, m1, b1.y));
+    v[5] = cmk(fma(-GF3_SQRT1_2, p1, b1.x), fma(-GF3_SQRT1_2, m1, b1.y));
     v[2] = cadd(b2, b6); v[6] = csub(b2, b6);
-    v[3] = cadd(b3, b7); v[7] = csub(b3, b7);
+    v[3] = cmk(fma(GF3_SQRT1_2, m3, b3.x), fma(-GF3_SQRT1_2, p3, b3.y));
+    v[7] = cmk(fma(-GF3_SQRT1_2, m3, b3.x), fma(GF3_SQRT1_2, p3, b3.y));
 }
 
 template <int R> GF3_DEV void bfly(cplx* v) { if constexpr (R == 8) bfly8(v); else bfly4(v); }
