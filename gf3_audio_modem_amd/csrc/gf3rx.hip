@@ -608,7 +608,7 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         asm volatile("" : "+v"(wb.x), "+v"(wb.y));
         rfft_regs<NC, PP, true>(v, lds, ft, wb, tq, z0, q & 1);       // slots hold 2 X: undone by `inv` below
 #pragma unroll
-        for (int s = 0; s < 8; ++s) acc[s] = cadd(acc[s], cmul_conj(v[s], hq[s]));
+        for (int s = 0; s < 8; ++s) acc[s] = cfma(v[s], cconj(hq[s]), acc[s]);        // acc += v conj(h): four fma
         if (tid == 0) {
             accDC += (z0.x + z0.y) * h0;
             accNy += (z0.x - z0.y) * hN;
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
             if (h >= 0 && h < a.Q) {
                 const cplx* H = a.Hq + (int64_t)h * (NC + 1);
 #pragma unroll
-                for (int s = 0; s < 8; ++s) acc[g][s] = cadd(acc[g][s], cmul_conj(x[s], H[Spec<NC>::bin(tid, s)]));
+                for (int s = 0; s < 8; ++s) acc[g][s] = cfma(x[s], cconj(H[Spec<NC>::bin(tid, s)]), acc[g][s]);
                 if (tid == 0) { dc[g] += x0 * H[0].x; ny[g] += xn * H[NC].x; }
             }
         }

@@ -140,6 +140,47 @@ template <int R> GF3_DEV void twiddle_mul(cplx* v, cplx w) {
     }
 }
 
+// Twiddle multiplication fused into the first butterfly stage: with x' = x w, the pair (a + b', a - b') costs
+// a complex fma (4) plus 2a - (a + b') (2) instead of a complex multiply, an add and a subtract (8); when a is
+// itself twiddled, 10 instead of 12.  Same powers-by-recurrence as twiddle_mul.
+GF3_DEV cplx cfma(cplx a, cplx w, cplx c) {           // c + a w
+    return cmk(fma(a.x, w.x, fma(-a.y, w.y, c.x)), fma(a.x, w.y, fma(a.y, w.x, c.y)));
+}
+GF3_DEV cplx twice_minus(cplx u, cplx s) { return cmk(fma(2.0, u.x, -s.x), fma(2.0, u.y, -s.y)); }   // 2u - s
+GF3_DEV void bfly4_tw(cplx* v, cplx w) {              // == twiddle_mul<4>(v, w); bfly4(v)
+    const double c2 = w.x + w.x;
+    const cplx w2 = cmk(fma(c2, w.x, -1.0), c2 * w.y);
+    const cplx w3 = tw_next(c2, w2, w);
+    const cplx s0 = cfma(v[2], w2, v[0]), s1 = twice_minus(v[0], s0);
+    const cplx u1 = cmul(v[1], w);
+    const cplx s2 = cfma(v[3], w3, u1), s3 = mul_negi(twice_minus(u1, s2));
+    v[0] = cadd(s0, s2); v[1] = cadd(s1, s3); v[2] = csub(s0, s2); v[3] = csub(s1, s3);
+}
+GF3_DEV void bfly8_tw(cplx* v, cplx w) {              // == twiddle_mul<8>(v, w); bfly8(v)
+    const double c2 = w.x + w.x;
+    const cplx w2 = cmk(fma(c2, w.x, -1.0), c2 * w.y);
+    const cplx w3 = tw_next(c2, w2, w), w4 = tw_next(c2, w3, w2), w5 = tw_next(c2, w4, w3);
+    const cplx w6 = tw_next(c2, w5, w4), w7 = tw_next(c2, w6, w5);
+    const cplx a0 = cfma(v[4], w4, v[0]), a1 = twice_minus(v[0], a0);
+    const cplx u2 = cmul(v[2], w2);
+    const cplx a2 = cfma(v[6], w6, u2), a3 = mul_negi(twice_minus(u2, a2));
+    const cplx u1 = cmul(v[1], w);
+    const cplx a4 = cfma(v[5], w5, u1), a5 = twice_minus(u1, a4);
+    const cplx u3 = cmul(v[3], w3);
+    const cplx a6 = cfma(v[7], w7, u3), a7 = mul_negi(twice_minus(u3, a6));
+    const cplx b0 = cadd(a0, a2), b1 = cadd(a1, a3), b2 = csub(a0, a2), b3 = csub(a1, a3);
+    const cplx b4 = cadd(a4, a6), o1 = cadd(a5, a7), b6 = mul_negi(csub(a4, a6)), o3 = csub(a5, a7);
+    const double p1 = o1.x + o1.y, m1 = o1.y - o1.x;
+    const double m3 = o3.y - o3.x, p3 = o3.x + o3.y;
+    v[0] = cadd(b0, b4); v[4] = csub(b0, b4);
+    v[1] = cmk(fma(GF3_SQRT1_2, p1, b1.x), fma(GF3_SQRT1_2, m1, b1.y));
+    v[5] = cmk(fma(-GF3_SQRT1_2, p1, b1.x), fma(-GF3_SQRT1_2, m1, b1.y));
+    v[2] = cadd(b2, b6); v[6] = csub(b2, b6);
+    v[3] = cmk(fma(GF3_SQRT1_2, m3, b3.x), fma(-GF3_SQRT1_2, p3, b3.y));
+    v[7] = cmk(fma(-GF3_SQRT1_2, m3, b3.x), fma(GF3_SQRT1_2, p3, b3.y));
+}
+template <int R> GF3_DEV void bfly_tw(cplx* v, cplx w) { if constexpr (R == 8) bfly8_tw(v, w); else bfly4_tw(v, w); }
+
 // ---------------------------------------------------------------- LDS FFT
 // LDS footprint of one FFT buffer, in cplx elements (first exchange is padded
 // by one element per 8 to break the stride-8 store conflict).
@@ -185,8 +226,7 @@ GF3_DEV void fft_pass(cplx (&v)[8], const cplx* src, cplx* dst, cplx wbase, cplx
         const int k = j & (NS - 1);
         cplx w = wbase;
         if (b == 1 && NS > T) w = cmul(wbase, wstep);      // k advances by T for the second butterfly
-        twiddle_mul<R>(&v[b * R], w);
-        bfly<R>(&v[b * R]);
+        bfly_tw<R>(&v[b * R], w);
         const int base = (j - k) * R + k;
 #pragma unroll
         for (int r = 0; r < R; ++r) dst[base + r * NS] = v[b * R + r];
@@ -245,9 +285,8 @@ GF3_DEV void real_split(cplx A, cplx Bm, cplx w, cplx& Xk, cplx& Xm) {
     const cplx B = cconj(Bm);
     const cplx E = TWICE ? cadd(A, B) : cscale(cadd(A, B), 0.5);
     const cplx D = TWICE ? csub(A, B) : cscale(csub(A, B), 0.5);
-    const cplx O = cmul(mul_negi(D), w);
-    Xk = cadd(E, O);
-    Xm = cconj(csub(E, O));
+    Xk = cfma(mul_negi(D), w, E);                    // E + O,  O = -i D w
+    Xm = cconj(twice_minus(E, Xk));                  // conj(E - O) = conj(2E - Xk)
 }
 
 // Passes through LDS.  In: v[r] = z[tid + r*NC/8].  ALL = false stops before the last pass
@@ -279,8 +318,7 @@ GF3_DEV cplx* fft_passes(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, int tid, 
     }
     {
         const int k = tid & 7;
-        twiddle_mul<8>(v, ft.b2);
-        bfly8(v);
+        bfly8_tw(v, ft.b2);
         const int base = (tid - k) * 8 + k;
 #pragma unroll
         for (int r = 0; r < 8; ++r) B[base + r * 8] = v[r];
@@ -341,10 +379,8 @@ GF3_DEV void rfft_regs(cplx (&v)[8], cplx* lds, const FftTw<NC>& ft, cplx wb, in
         cplx a[4], b[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { a[r] = Z[t + r * Q]; b[r] = Z[j2 + r * Q]; }
-        twiddle_mul<4>(a, ft.b4);
-        twiddle_mul<4>(b, ft.c4);
-        bfly4(a);
-        bfly4(b);
+        bfly4_tw(a, ft.b4);
+        bfly4_tw(b, ft.c4);
         z0 = a[0];
         // Only thread 0 pairs its outputs differently (its two butterflies mirror onto themselves).  The ~40 selects
         // that costs are confined to its wave by a scalar branch; the other waves run the plain pairing.
