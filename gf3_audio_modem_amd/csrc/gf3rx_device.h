@@ -92,12 +92,6 @@ GF3_DEV double load_sample_clamped(const void* p, int64_t i, int64_t n, int dt) 
 // ---------------------------------------------------------------- butterflies
 #define GF3_SQRT1_2 0.70710678118654752440
 
-GF3_DEV void bfly4(cplx* v) {
-    const cplx s0 = cadd(v[0], v[2]), s1 = csub(v[0], v[2]);
-    const cplx s2 = cadd(v[1], v[3]), s3 = mul_negi(csub(v[1], v[3]));
-    v[0] = cadd(s0, s2); v[1] = cadd(s1, s3); v[2] = csub(s0, s2); v[3] = csub(s1, s3);
-}
-
 GF3_DEV void bfly8(cplx* v) {
     const cplx a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]);
     const cplx a2 = cadd(v[2], v[6]), a3 = mul_negi(csub(v[2], v[6]));
@@ -116,38 +110,18 @@ GF3_DEV void bfly8(cplx* v) {
     v[7] = cmk(fma(-GF3_SQRT1_2, m3, b3.x), fma(GF3_SQRT1_2, p3, b3.y));
 }
 
-template <int R> GF3_DEV void bfly(cplx* v) { if constexpr (R == 8) bfly8(v); else bfly4(v); }
-
 // powers of a unit twiddle w = exp(-i t) by the three-term recurrence w^(k+1) = 2 cos(t) w^k - w^(k-1): two fma per
 // power instead of the four operations of a complex multiply, no table traffic.  Its error grows like k^2 ulp
 // (k <= 7 here: <= ~1e-14 relative, three orders inside the tightest parity bar).
 GF3_DEV cplx tw_next(double c2, cplx wk, cplx wkm1) { return cmk(fma(c2, wk.x, -wkm1.x), fma(c2, wk.y, -wkm1.y)); }
-template <int R> GF3_DEV void twiddle_mul(cplx* v, cplx w) {
-    const double c2 = w.x + w.x;
-    const cplx w2 = cmk(fma(c2, w.x, -1.0), c2 * w.y);
-    v[1] = cmul(v[1], w);
-    v[2] = cmul(v[2], w2);
-    const cplx w3 = tw_next(c2, w2, w);
-    v[3] = cmul(v[3], w3);
-    if constexpr (R == 8) {
-        const cplx w4 = tw_next(c2, w3, w2);
-        v[4] = cmul(v[4], w4);
-        const cplx w5 = tw_next(c2, w4, w3);
-        v[5] = cmul(v[5], w5);
-        const cplx w6 = tw_next(c2, w5, w4);
-        v[6] = cmul(v[6], w6);
-        v[7] = cmul(v[7], tw_next(c2, w6, w5));
-    }
-}
-
 // Twiddle multiplication fused into the first butterfly stage: with x' = x w, the pair (a + b', a - b') costs
 // a complex fma (4) plus 2a - (a + b') (2) instead of a complex multiply, an add and a subtract (8); when a is
-// itself twiddled, 10 instead of 12.  Same powers-by-recurrence as twiddle_mul.
+// itself twiddled, 10 instead of 12.
 GF3_DEV cplx cfma(cplx a, cplx w, cplx c) {           // c + a w
     return cmk(fma(a.x, w.x, fma(-a.y, w.y, c.x)), fma(a.x, w.y, fma(a.y, w.x, c.y)));
 }
 GF3_DEV cplx twice_minus(cplx u, cplx s) { return cmk(fma(2.0, u.x, -s.x), fma(2.0, u.y, -s.y)); }   // 2u - s
-GF3_DEV void bfly4_tw(cplx* v, cplx w) {              // == twiddle_mul<4>(v, w); bfly4(v)
+GF3_DEV void bfly4_tw(cplx* v, cplx w) {              // v[r] *= w^r, then the radix-4 butterfly
     const double c2 = w.x + w.x;
     const cplx w2 = cmk(fma(c2, w.x, -1.0), c2 * w.y);
     const cplx w3 = tw_next(c2, w2, w);
@@ -156,7 +130,7 @@ GF3_DEV void bfly4_tw(cplx* v, cplx w) {              // == twiddle_mul<4>(v, w)
     const cplx s2 = cfma(v[3], w3, u1), s3 = mul_negi(twice_minus(u1, s2));
     v[0] = cadd(s0, s2); v[1] = cadd(s1, s3); v[2] = csub(s0, s2); v[3] = csub(s1, s3);
 }
-GF3_DEV void bfly8_tw(cplx* v, cplx w) {              // == twiddle_mul<8>(v, w); bfly8(v)
+GF3_DEV void bfly8_tw(cplx* v, cplx w) {              // v[r] *= w^r, then the radix-8 butterfly
     const double c2 = w.x + w.x;
     const cplx w2 = cmk(fma(c2, w.x, -1.0), c2 * w.y);
     const cplx w3 = tw_next(c2, w2, w), w4 = tw_next(c2, w3, w2), w5 = tw_next(c2, w4, w3);
