@@ -652,9 +652,16 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
     for (int j = tid; j < W; j += T) mx = fmax(mx, y[j]);
     mx = block_max(mx, scratch);
     int first = 0x7fffffff;
+    // Lags that cannot reach the threshold skip the three divisions (y < thresh*max*(1-1e-6) implies
+    // fl(y/max) < thresh; same prefilter as pk_candidates): only the few lags around the peak pay for them.
+    const bool filt = mx > 0.0 && a.thresh > 0.0 && mx < INFINITY && a.thresh < INFINITY;
+    const double lim = filt ? a.thresh * mx * (1.0 - 1e-6) : -INFINITY;
     for (int j = 1 + tid; j < W - 1; j += T) {
-        const double pm1 = y[j - 1] / mx, p0 = y[j] / mx, pp1 = y[j + 1] / mx;
-        if (((p0 - pm1) * (pp1 - p0) <= 0.0) && (p0 > a.thresh)) first = min(first, j);
+        const double y0 = y[j];
+        if (!(y0 < lim)) {
+            const double pm1 = y[j - 1] / mx, p0 = y0 / mx, pp1 = y[j + 1] / mx;
+            if (((p0 - pm1) * (pp1 - p0) <= 0.0) && (p0 > a.thresh)) first = min(first, j);
+        }
     }
     first = block_min_i(first, (int*)(scratch + 16));
     if (tid == 0) {
