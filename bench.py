@@ -33,6 +33,49 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 WIN_LO = -8                    # search window = chirp-start lags [-8, window-8): jitter gaps 0..299 are interior points
 
 
+class PowerSampler:
+    """Package power of this process's GPU while the timed loop runs, read from the amdgpu hwmon node in sysfs
+    (plain file reads from a thread: nothing is executed).  median_w is None when the node cannot be found."""
+
+    def __init__(self, dev_index):
+        import glob, threading
+        self.path, self.samples, self._stop = None, [], threading.Event()
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            for card in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.realpath(card).endswith(bdf):
+                    hits = glob.glob(os.path.join(card, "hwmon", "hwmon*", "power1_input")) + \
+                           glob.glob(os.path.join(card, "hwmon", "hwmon*", "power1_average"))
+                    if hits:
+                        self.path = hits[0]
+        except Exception:
+            self.path = None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(int(open(self.path).read()) * 1e-6)
+            except Exception:
+                pass
+            self._stop.wait(0.02)
+
+    def __enter__(self):
+        if self.path:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.path:
+            self._thread.join()
+
+    @property
+    def median_w(self):
+        return float(np.median(self.samples)) if self.samples else None
+
+
 def build_workload(args, rank):
     """F distinct frame buffers, synthesised on the device by the engine's own transmit kernel
     (gf3_tx_frames): random payload, jitter gap 0..299 before each chirp, QPSK filler on the one
@@ -226,10 +269,12 @@ def main():
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     gd.barrier()
     torch.cuda.synchronize()
+    power = PowerSampler(local)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        starts = step(evs[k])
-    torch.cuda.synchronize()
+    with power:
+        for k in range(args.steps):
+            starts = step(evs[k])
+        torch.cuda.synchronize()
     gd.barrier()
     dt = time.perf_counter() - t0
     dt = gd.max_over_ranks(dt, dev)
@@ -293,8 +338,9 @@ def main():
             "roofline": {"kernel": "demod_kernel<2048,f32,MODE_QPSK>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_demod, "avg_launch_ms": t_demod * 1e3,
-                         "limiter": "package power: 1.38 kW of the 1.4 kW cap while this runs (rocm-smi), energy dominated "
-                                    "by the fp64 operation count of the transforms (DESIGN.md section 8)"},
+                         "limiter": "package power (cap 1.4 kW): energy dominated by the fp64 operation count of the "
+                                    "transforms (DESIGN.md section 8)",
+                         "package_power_w_during_timed_loop": power.median_w},
             "roofline_sync": {"kernel": "corr_kernel<1024,f32> (15 x 2048-point transforms per packet)", "bound": "hbm", "achieved": bytes_sync / t_sync / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_sync / t_sync / 1e9 / HBM_PEAK_GBS,
                               "algorithmic_bytes_per_launch": bytes_sync, "avg_launch_ms": t_sync * 1e3},
