@@ -340,7 +340,8 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_demod, "avg_launch_ms": t_demod * 1e3,
                          "limiter": "package power (cap 1.4 kW): energy dominated by the fp64 operation count of the "
                                     "transforms (DESIGN.md section 8)",
-                         "package_power_w_during_timed_loop": power.median_w},
+                         "package_power_w_during_timed_loop": power.median_w,
+                         "energy_nJ_per_sample": (power.median_w * dt / args.steps / n_samples * 1e9) if power.median_w else None},
             "roofline_sync": {"kernel": "corr_kernel<1024,f32> (15 x 2048-point transforms per packet)", "bound": "hbm", "achieved": bytes_sync / t_sync / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_sync / t_sync / 1e9 / HBM_PEAK_GBS,
                               "algorithmic_bytes_per_launch": bytes_sync, "avg_launch_ms": t_sync * 1e3},
