@@ -575,7 +575,7 @@ def test_bench_json_contract(capsys, monkeypatch):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("gf3_bench", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--frames", "1024", "--steps", "2", "--warmup", "1", "--no-cpu"])
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--frames", "1024", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-power"])
     monkeypatch.delenv("WORLD_SIZE", raising=False)
     bench.main()
     line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
