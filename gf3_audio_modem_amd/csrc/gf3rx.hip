@@ -605,7 +605,8 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         double h0 = 0.0, hN = 0.0;
         if (tid == 0) { h0 = Hq[0].x; hN = Hq[NC].x; }
         ft.refresh();
-        asm volatile("" : "+v"(wb.x), "+v"(wb.y));
+        // (wb is left visible to the optimiser here: the four pair twiddles of the split are loop invariants of the
+        //  partition loop and this kernel has the 12 registers to keep them)
         rfft_regs<NC, PP, true>(v, lds, ft, wb, tq, z0, q & 1);       // slots hold 2 X: undone by `inv` below
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[s] = cfma(v[s], cconj(hq[s]), acc[s]);        // acc += v conj(h): four fma
