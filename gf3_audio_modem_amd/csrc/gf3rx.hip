@@ -604,7 +604,7 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec<NC>::bin(tq, s)];
         double h0 = 0.0, hN = 0.0;
         if (tid == 0) { h0 = Hq[0].x; hN = Hq[NC].x; }
-        ft.refresh();
+        if constexpr (NC <= 1024) ft.refresh_inner(); else ft.refresh();      // (larger plans have no registers to spare)
         // (wb is left visible to the optimiser here: the four pair twiddles of the split are loop invariants of the
         //  partition loop and this kernel has the 12 registers to keep them)
         rfft_regs<NC, PP, true>(v, lds, ft, wb, tq, z0, q & 1);       // slots hold 2 X: undone by `inv` below

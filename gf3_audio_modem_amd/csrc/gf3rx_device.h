@@ -179,7 +179,9 @@ template <int NC> struct FftTw {
     GF3_DEV void refresh() {
         asm volatile("" : "+v"(b2.x), "+v"(b2.y), "+v"(b3.x), "+v"(b3.y));
         asm volatile("" : "+v"(b4.x), "+v"(b4.y), "+v"(c4.x), "+v"(c4.y));
-    }      // c4: step to the second butterfly of a 2-butterfly pass, or (fused
+    }
+    // passes 2 and 3 only: a kernel with ~16 registers to spare lets the (few) last-pass powers be hoisted
+    GF3_DEV void refresh_inner() { asm volatile("" : "+v"(b2.x), "+v"(b2.y), "+v"(b3.x), "+v"(b3.y)); }      // c4: step to the second butterfly of a 2-butterfly pass, or (fused
                               // sizes) the base twiddle of the mirrored butterfly of the last pass
     GF3_DEV void init(int tid, const cplx* __restrict__ tw);
 };
