@@ -600,14 +600,23 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         // this partition's chirp spectrum, requested before the transform: the barriers' memory clobber keeps the
         // compiler from moving these loads up itself, and their L2 latency would sit between transform and MAC
         cplx hq[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec<NC>::bin(tq, s)];
         double h0 = 0.0, hN = 0.0;
-        if (tid == 0) { h0 = Hq[0].x; hN = Hq[NC].x; }
-        if constexpr (NC <= 1024) ft.refresh_inner(); else ft.refresh();      // (larger plans have no registers to spare)
-        // (wb is left visible to the optimiser here: the four pair twiddles of the split are loop invariants of the
-        //  partition loop and this kernel has the 12 registers to keep them)
+        constexpr bool HOIST = (NC <= 1024 && DT != DT_F64);      // (f64 samples: the prefetch needs the registers)
+        if constexpr (!HOIST) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec<NC>::bin(tq, s)];
+            if (tid == 0) { h0 = Hq[0].x; hN = Hq[NC].x; }
+            ft.refresh();
+        }
+        // Frames plan with narrow samples (HOIST): nothing is made opaque, so every twiddle power and the split's pair twiddles are
+        // loop invariants kept in registers across the partition loop (~45 registers, ~30 fp64 operations per
+        // partition saved); the registers come from loading the chirp spectrum after the transform instead of before.
         rfft_regs<NC, PP, true>(v, lds, ft, wb, tq, z0, q & 1);       // slots hold 2 X: undone by `inv` below
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec<NC>::bin(tq, s)];
+            if (tid == 0) { h0 = Hq[0].x; hN = Hq[NC].x; }
+        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) acc[s] = cfma(v[s], cconj(hq[s]), acc[s]);        // acc += v conj(h): four fma
         if (tid == 0) {
