@@ -249,9 +249,11 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     auto sym_pos = [&](int i) { return i < P ? i : (i < 2 * P ? D + i : i - P); };
     RawPair<DT> nxt[8];
     auto fetch = [&](int i) {
-        const int64_t s0 = off + (int64_t)sym_pos(i) * S + a.CP + 2 * launder(tid);
+        typedef typename RawT<DT>::E E;
+        const E* base = (const E*)a.in + (off + (int64_t)sym_pos(i) * S + a.CP);      // wave-uniform
+        const unsigned t2 = 2u * (unsigned)launder(tid);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) nxt[r].load(a.in, s0 + 2 * (int64_t)(r * T));
+        for (int r = 0; r < 8; ++r) nxt[r].load_u(base, t2 + 2u * (unsigned)(r * T));
     };
     const int Msym = 2 * P + D;
     cplx v[8], z0;
@@ -573,11 +575,12 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         if (inside && need >= 14 * T) {
             // common case: the segment lies inside the buffer and only the last of the eight
             // strided loads can reach past the samples that matter (j >= need)
-            const int64_t base = seg + 2 * tid;
+            const E* base = (const E*)a.in + seg;                        // wave-uniform
+            const unsigned t2 = 2u * (unsigned)tid;
 #pragma unroll
-            for (int r = 0; r < 7; ++r) nxt[r].load(a.in, base + 2 * (int64_t)(r * T));
+            for (int r = 0; r < 7; ++r) nxt[r].load_u(base, t2 + 2u * (unsigned)(r * T));
             const int j = 2 * (tid + 7 * T);
-            if (j + 1 < need) nxt[7].load(a.in, seg + j);
+            if (j + 1 < need) nxt[7].load_u(base, (unsigned)j);
             else { nxt[7].zero(); if (j < need) nxt[7].v.a = ((const E*)a.in)[seg + j]; }
             return;
         }

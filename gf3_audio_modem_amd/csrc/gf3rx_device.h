@@ -67,6 +67,9 @@ template <int DT> struct RawPair {
     struct __attribute__((packed, aligned(sizeof(E)))) P2 { E a, b; };
     P2 v;
     GF3_DEV void load(const void* p, int64_t i) { v = *(const P2*)((const E*)p + i); }
+    // wave-uniform base + 32-bit per-lane element offset: selects the scalar-base addressing form of global_load
+    // (one 32-bit VGPR offset) instead of 64-bit per-lane address arithmetic
+    GF3_DEV void load_u(const E* base, unsigned off) { v = *(const P2*)(base + off); }
     GF3_DEV void zero() { v.a = 0; v.b = 0; }
     GF3_DEV cplx get() const { return cmk((double)v.a, (double)v.b); }
 };
