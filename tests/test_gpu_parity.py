@@ -590,3 +590,30 @@ def test_bench_json_contract(capsys, monkeypatch):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert d["ber"] == 0.0 and d["sync_exact"] is True and "cpu_baseline" not in d
     assert abs(d["value"] - 1024 * 78720 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("seed,tail", [(1, 500), (2, 1), (3, 4000)])
+def test_stream_peak_picking_on_dense_candidates(seed, tail):
+    """Noise-dominated streams: thousands of candidates above 0.4 max, so the candidate compaction runs over many
+    blocks and the NMS over several LDS chunks with long successor chains.  The peak-picking kernels are checked in
+    isolation: the reference rule (oracle.pick_peaks) applied to the engine's OWN correlation must give the same
+    indices -- including the except-branch wipe when a chirp ends within the last two samples (tail = 1)."""
+    import dataclasses
+    g = load("g1_n1024_qpsk")
+    p = dataclasses.replace(params_of(g), thresh=0.1)               # low threshold: noise extrema qualify in their thousands
+    rs = np.random.RandomState(seed)
+    c = orc.chirp_replica(p)
+    n = 400_000
+    r = 0.05 * rs.randn(n)
+    for pos in (3000, 120_000, 250_000):
+        r[pos: pos + p.Lc] += 0.007 * c / np.abs(c).max()           # chirps barely above the noise maximum
+    r[n - tail - p.Lc: n - tail] += 0.01 * c / np.abs(c).max()      # a chirp ending `tail` samples before the end
+    eng = engine_for(p, thresh=p.thresh)
+    x = torch.from_numpy(r).cuda()
+    peaks, corr = eng.sync_stream(x, cap=4096, want_corr=True)
+    P = corr.cpu().numpy()
+    zeros = orc.pick_peaks(P.copy(), p.Lc, n, p.thresh)
+    want = np.flatnonzero(zeros)
+    assert np.array_equal(peaks.cpu().numpy(), want)
+    ncand = int(np.count_nonzero((np.diff(P / P.max())[:-1] * np.diff(P / P.max())[1:] <= 0) & ((P / P.max())[1:-1] > p.thresh)))
+    assert ncand > 4096                                              # the case really is dense (several NMS chunks)
