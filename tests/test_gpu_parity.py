@@ -508,6 +508,13 @@ def test_abi_error_paths():
         eng.tx_frames(np.zeros((2, eng.bytes_per_frame), np.uint8), np.zeros(511, complex), stride=100)
     with pytest.raises(ValueError, match="shapes"):
         eng.equalise(np.zeros((1, 8, 10), complex), np.zeros((1, 2, 511), complex), np.zeros((1, 2, 511), complex))
+    # more detections than the caller's peak buffer holds: GF3_ERANGE with the true count in the message
+    from gf3_audio_modem_amd.engine import Gf3Error
+    g = load("g1_n1024_qpsk")
+    e1 = engine_for(params_of(g))
+    with pytest.raises(Gf3Error, match="exceed capacity"):
+        e1.sync_stream(torch.from_numpy(g["r"]).cuda(), cap=2)
+    assert e1.sync_stream(torch.from_numpy(g["r"]).cuda(), cap=3).numel() == 3        # exactly enough is fine
 
 
 def test_schmidl_cox_metric():
