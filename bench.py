@@ -12,6 +12,11 @@ scaling), each frame a row of `stride` fp32 samples = [jitter gap 0..299 | chirp
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...      (not under torchrun: starts its own N rank processes, see launch_ranks)
+
+N = 1 is BASELINE config 2 (65 536 frames); N > 1 is BASELINE config 4 (131 072 frames per GPU = 1 048 576 at
+N = 8, weak scaling), timed with the per-chunk overlapped all-gather (`value`) and again with the literal single
+all-gather of the north_star (`single_gather`).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for
 the dominant kernel (demod_kernel) and `cpu_baseline` (the NumPy oracle, 1 thread, on
@@ -180,12 +185,106 @@ def cpu_baseline(cfg, rows_dev, payload_dev, window, target_s):
                       f"(NumPy restatement of OFDM.py, 1 thread), {dt:.1f} s, payload recovered: {ok}"}
 
 
+def _event_ms(fn, reps, warm=2):
+    """mean HIP-event time of `fn` (one launch on the current stream) over `reps` launches, in ms"""
+    for _ in range(warm):
+        fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+
+def config5_rooflines(dev, log2_samples=28, log2_symbols=26, reps=5):
+    """BASELINE config 5, sized past the 256 MB Infinity Cache so that the figure is an HBM figure: per N in
+    {1024, 2048, 4096, 8192} ONE launch of rfft_kernel over 2^28 f32 samples (1 GiB in, 2.1 GB of complex128 bins
+    out, > 0.3 ms), and one launch of the 64-QAM soft demapper over 2^26 symbols (1 GiB in, 1.6 GB of f32 LLRs out).
+    Algorithmic bytes per SURVEY 8(d): B_in N + 16 (N/2+1) per transform; 16 + 4 mu per symbol."""
+    from gf3_audio_modem_amd import Engine, RxConfig, qpsk_table, square_qam_table
+    total = 1 << log2_samples
+    gen = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(total, dtype=torch.float32, device=dev, generator=gen)
+    out = {"roofline_rfft": {}}
+    pts, bt = qpsk_table()
+    for N in (1024, 2048, 4096, 8192):
+        K = N // 2 - 1
+        eng = Engine(RxConfig(N=N, CP=0, P=1, D=1, data_bins=np.arange(1, K), const_points=pts, const_bits=bt,
+                              known_bits=np.zeros(2 * K, np.uint8), in_dtype=torch.float32, fit_lo=10, fit_hi=100))
+        n_sym = total // N
+        off = torch.arange(n_sym, dtype=torch.int64, device=dev) * N
+        X = torch.empty((n_sym, N // 2 + 1), dtype=torch.complex128, device=dev)
+        ms = _event_ms(lambda: eng.rfft_batch(x, off, out=X), reps)
+        rows = [0, n_sym // 2 + 1, n_sym - 1]
+        ref = np.fft.rfft(np.stack([x[r * N:(r + 1) * N].cpu().numpy().astype(np.float64) for r in rows]))
+        err = float(np.abs(X[rows].cpu().numpy() - ref).max() / np.abs(ref).max())
+        by = n_sym * (4 * N + 16 * (N // 2 + 1))
+        out["roofline_rfft"][f"N{N}"] = {"kernel": f"rfft_kernel<{N // 2},f32>", "bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by,
+                                         "avg_launch_ms": ms, "transforms_per_launch": n_sym, "max_rel_err_vs_numpy_fft": err}
+        del X, off
+        eng.close()
+    del x
+    n = 1 << log2_symbols
+    pts6, bt6 = square_qam_table(6)
+    eng = Engine(RxConfig(N=1024, CP=0, P=1, D=1, data_bins=np.arange(1, 511), const_points=pts6, const_bits=bt6,
+                          known_bits=np.zeros(511 * 6, np.uint8), in_dtype=torch.float32, fit_lo=10, fit_hi=100))
+    idx = torch.randint(0, 64, (n,), device=dev, generator=gen)
+    sym = torch.as_tensor(pts6, device=dev)[idx] + 0.08 * torch.complex(torch.randn(n, dtype=torch.float64, device=dev, generator=gen),
+                                                                      torch.randn(n, dtype=torch.float64, device=dev, generator=gen))
+    llr = torch.empty((n, 6), dtype=torch.float32, device=dev)
+    ms = _event_ms(lambda: eng.soft_demap(sym, 0.0128, out=llr), reps)
+    hard, _ = eng.demap_hard(sym[: 1 << 20])
+    sign_ok = bool(torch.equal((llr[: 1 << 20] < 0).to(torch.uint8), hard))
+    by = n * (16 + 4 * 6)
+    out["roofline_soft_demap"] = {"kernel": "soft_demap_sep_kernel<6> (64-QAM)", "bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by,
+                                  "avg_launch_ms": ms, "symbols_per_launch": n, "sign_equals_hard_decision": sign_ok}
+    eng.close()
+    return out
+
+
+def stream_sync_roofline(dev, frames=4096):
+    """BASELINE config 3 (tools/config3.py): 4 096 16-QAM packets as ONE stream through the measured 30-tap channel,
+    stream-mode chirp sync with the reference's global-max / first-extremum / suppression rule, then demod.
+    Algorithmic bytes of the sync: B_in per sample in, 8 B per detected peak out."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gf3_config3", os.path.join(ROOT, "tools", "config3.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    eng, cfg, channel = tool.make_engine()
+    r, payload = tool.make_stream(eng, channel, frames)
+    res, starts, _ = tool.measure(eng, cfg, r, payload, reps=3)
+    by = 4 * r.numel() + 8 * (frames + 1)
+    t = res["sync_stream_s"]
+    out = {"roofline_stream_sync": {"kernel": "gf3_sync_stream (config 3: one 321 M-sample stream, 4 096 packets)", "bound": "hbm",
+                                    "achieved": by / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS,
+                                    "algorithmic_bytes_per_call": by, "call_ms": t * 1e3, "demod_ms": res["demod_s"] * 1e3,
+                                    "samples_per_s_sync_plus_demod": res["samples_per_s"], "ber_vs_payload": res["ber"],
+                                    "sync_offsets_exact": res["sync_offsets_as_expected_plus1"]}}
+    eng.close()
+    return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: the parent, which has not touched the GPU, starts N fresh
+    copies of this script as child processes (one per rank, torchrun's environment, rendezvous on 127.0.0.1),
+    relays rank 0's JSON line, and returns a non-zero code if any rank failed.  No os.exec*."""
+    from gf3_audio_modem_amd.dist import spawn_ranks
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    if os.environ.get("GF3_BENCH_RANK_CMD"):             # tests: a stub in place of the rank program
+        cmd = json.loads(os.environ["GF3_BENCH_RANK_CMD"]) + sys.argv[1:]
+    rc, _ = spawn_ranks(cmd, n)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=65536, help="frames per GPU")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="frames per GPU (default: 65 536 at N=1 = BASELINE config 2; 131 072 at N>1 = config 4)")
     ap.add_argument("--stride", type=int, default=78720)
     ap.add_argument("--window", type=int, default=320)
     ap.add_argument("--chunks", type=int, default=8, help="N>1: pieces the batch is cut into to overlap the all-gather")
@@ -195,7 +294,13 @@ def main():
     ap.add_argument("--rehearse-chunked", action="store_true",
                     help="N=1 only: run the N>1 code path (chunked launches, per-chunk all-gather on a side stream) "
                          "through a one-rank RCCL group; a rehearsal of the multi-GPU path, not the headline number")
+    ap.add_argument("--no-config5", action="store_true", help="skip the config-5 rFFT / soft-demap roofline legs (N=1)")
+    ap.add_argument("--no-stream", action="store_true", help="skip the config-3 stream-sync roofline leg (N=1)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))        # the children run the rest of main() with WORLD_SIZE set
+    if args.frames <= 0:
+        args.frames = 65536 if args.gpus == 1 else 131072
 
     pool = cores = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu and not args.rehearse_chunked:
@@ -217,93 +322,126 @@ def main():
     eng, cfg, big, payload, gaps = build_workload(args, rank)
     F = args.frames
     n_samples = F * args.stride
-    bits = torch.empty((F, eng.bytes_per_frame), dtype=torch.uint8, device=dev)
-    gathered = torch.empty((F * world, eng.bytes_per_frame), dtype=torch.uint8, device=dev) if multi else None
-    chunks = args.chunks if (multi and F % args.chunks == 0) else 1
-    Fc = F // chunks
-    og = gd.OverlappedGather(gathered, F, chunks) if multi else None
-    starts_all = torch.empty((F,), dtype=torch.int64, device=dev)
-    starts_c = torch.empty((chunks, Fc), dtype=torch.int64, device=dev)      # per-chunk sync results (chunk-relative)
-    s_sync = torch.cuda.Stream() if multi else None      # chunked path: sync kernels run ahead on their own stream
-    s_dem2 = torch.cuda.Stream() if multi else None      # ... and odd chunks' demod kernels on a second one
-    ev_sync = [torch.cuda.Event() for _ in range(chunks)]
-    ev_step = torch.cuda.Event()
-
-    def step(ev=None):
-        """N=1: one launch of each kernel over the whole batch.  N>1: per chunk, sync + demod on
-        this rank's rows, then that chunk's packed bits are all-gathered on a side stream."""
-        if not multi:
-            if ev: ev[0].record()
-            starts = eng.sync_frames(big, F, args.stride, WIN_LO, WIN_LO + args.window)
-            if ev: ev[1].record()
-            eng.demod_frames(big, starts, out_bits=bits)
-            if ev: ev[2].record()
-            return starts
-        # the sync launches of all chunks go to their own stream and run ahead; demod of chunk c waits for its
-        # sync only, so the two kernel families overlap and a chunk boundary costs no drained-GPU tail
-        main = torch.cuda.current_stream()
-        ev_step.record(main)
-        s_sync.wait_event(ev_step)                        # previous step's demods are done with starts_c
-        with torch.cuda.stream(s_sync):
-            for c in range(chunks):
-                if ev and c == 0: ev[0].record()
-                eng.sync_frames(big[c * Fc:(c + 1) * Fc], Fc, args.stride, WIN_LO, WIN_LO + args.window, out_starts=starts_c[c])
-                if ev and c == 0: ev[1].record()
-                ev_sync[c].record()
-        s_dem2.wait_event(ev_step)
-        for c in range(chunks):                           # demod of consecutive chunks on alternating streams: the tail
-            with torch.cuda.stream(main if c % 2 == 0 else s_dem2):      # of one launch overlaps the head of the next
-                torch.cuda.current_stream().wait_event(ev_sync[c])
-                if ev and c == 0: ev[3].record()
-                eng.demod_frames(big[c * Fc:(c + 1) * Fc], starts_c[c], out_bits=bits[c * Fc:(c + 1) * Fc])
-                if ev and c == 0: ev[2].record()
-                og.chunk_done(c, bits[c * Fc:(c + 1) * Fc])
-        main.wait_stream(s_dem2)
-        main.wait_stream(s_sync)
-        torch.add(starts_c, (torch.arange(chunks, device=dev, dtype=torch.int64) * (Fc * args.stride))[:, None],
-                  out=starts_all.view(chunks, Fc))
-        og.finish()
-        return starts_all
-
-    for _ in range(args.warmup):
-        step()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
-    gd.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        starts = step(evs[k])
-    torch.cuda.synchronize()
-    gd.barrier()
-    dt = time.perf_counter() - t0
-    dt = gd.max_over_ranks(dt, dev)
-
-    # correctness of what was just timed: EVERY frame decodes to its payload, every sync offset exact
-    bit_errors = int(torch.count_nonzero(torch.bitwise_xor(bits, payload)).item())   # differing bytes (0 => BER 0)
-    if bit_errors:
-        x = torch.bitwise_xor(bits, payload).cpu().numpy()
-        bit_errors = int(np.unpackbits(x).sum())
     exp_starts = torch.arange(F, device=dev, dtype=torch.int64) * args.stride + gaps + cfg.chirp_length
-    sync_ok = bool(torch.equal(starts, exp_starts))
-    gather_ok = None
-    if multi:           # every rank must hold every rank's bits, in the block-cyclic global order
-        import torch.distributed as tdist
-        mine = gd.cyclic_frame_index(rank, world, F, chunks).to(dev)
-        gather_ok = bool(torch.equal(gathered[mine], bits))
-        # ... and this rank's copy of every OTHER rank's rows matches what that rank decoded (a checksum of each
-        # rank's rows, weighted by row number, is exchanged and recomputed on the local copy)
-        w = (torch.arange(F, device=dev, dtype=torch.int64) % 65521 + 1)[:, None]
-        def checksum(rows):
-            return (rows.to(torch.int64) * w).sum()
-        sums = torch.zeros(world, dtype=torch.int64, device=dev)
-        sums[rank] = checksum(bits)
-        tdist.all_reduce(sums, op=tdist.ReduceOp.SUM)
-        for r in range(world):
-            idx = gd.cyclic_frame_index(r, world, F, chunks).to(dev)
-            gather_ok = gather_ok and bool(checksum(gathered[idx]) == sums[r])
-        flag = torch.tensor([1.0 if gather_ok else 0.0], dtype=torch.float64, device=dev)
-        tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
-        gather_ok = bool(flag.item() == 1.0)
+
+    class Run:
+        """One way of running the step: N=1 (one launch of each kernel over the whole batch) or N>1 with the batch
+        cut into `chunks` pieces whose packed bits are all-gathered on a side stream as soon as they exist
+        (chunks = 1: the literal single all-gather after the kernels)."""
+
+        def __init__(self, chunks):
+            self.chunks = chunks if (multi and F % chunks == 0) else 1
+            self.Fc = F // self.chunks
+            self.bits = torch.empty((F, eng.bytes_per_frame), dtype=torch.uint8, device=dev)
+            self.gathered = torch.empty((F * world, eng.bytes_per_frame), dtype=torch.uint8, device=dev) if multi else None
+            self.og = gd.OverlappedGather(self.gathered, F, self.chunks) if multi else None
+            self.starts_all = torch.empty((F,), dtype=torch.int64, device=dev)
+            self.starts_c = torch.empty((self.chunks, self.Fc), dtype=torch.int64, device=dev)   # per-chunk sync results (chunk-relative)
+            self.s_sync = torch.cuda.Stream() if multi else None      # chunked path: sync kernels run ahead on their own stream
+            self.s_dem2 = torch.cuda.Stream() if multi else None      # ... and odd chunks' demod kernels on a second one
+            self.ev_sync = [torch.cuda.Event() for _ in range(self.chunks)]
+            self.ev_step = torch.cuda.Event()
+            self.chunk_base = (torch.arange(self.chunks, device=dev, dtype=torch.int64) * (self.Fc * args.stride))[:, None]
+
+        def step(self, ev=None):
+            if not multi:
+                if ev: ev[0].record()
+                starts = eng.sync_frames(big, F, args.stride, WIN_LO, WIN_LO + args.window, out_starts=self.starts_all)
+                if ev: ev[1].record()
+                eng.demod_frames(big, starts, out_bits=self.bits)
+                if ev: ev[2].record()
+                return starts
+            chunks, Fc = self.chunks, self.Fc
+            # the sync launches of all chunks go to their own stream and run ahead; demod of chunk c waits for its
+            # sync only, so the two kernel families overlap and a chunk boundary costs no drained-GPU tail
+            main = torch.cuda.current_stream()
+            self.ev_step.record(main)
+            self.s_sync.wait_event(self.ev_step)                   # previous step's demods are done with starts_c
+            with torch.cuda.stream(self.s_sync):
+                for c in range(chunks):
+                    if ev and c == 0: ev[0].record()
+                    eng.sync_frames(big[c * Fc:(c + 1) * Fc], Fc, args.stride, WIN_LO, WIN_LO + args.window, out_starts=self.starts_c[c])
+                    if ev and c == 0: ev[1].record()
+                    self.ev_sync[c].record()
+            self.s_dem2.wait_event(self.ev_step)
+            for c in range(chunks):                           # demod of consecutive chunks on alternating streams: the tail
+                with torch.cuda.stream(main if c % 2 == 0 else self.s_dem2):   # of one launch overlaps the head of the next
+                    torch.cuda.current_stream().wait_event(self.ev_sync[c])
+                    if ev and c == 0: ev[3].record()
+                    eng.demod_frames(big[c * Fc:(c + 1) * Fc], self.starts_c[c], out_bits=self.bits[c * Fc:(c + 1) * Fc])
+                    if ev and c == 0: ev[2].record()
+                    self.og.chunk_done(c, self.bits[c * Fc:(c + 1) * Fc])
+            main.wait_stream(self.s_dem2)
+            main.wait_stream(self.s_sync)
+            torch.add(self.starts_c, self.chunk_base, out=self.starts_all.view(chunks, Fc))
+            self.og.finish()
+            return self.starts_all
+
+        def timed(self, warmup, steps):
+            """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides;
+            returns (seconds = max over ranks, per-step event sets)."""
+            for _ in range(warmup):
+                self.step()
+            evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+            gd.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                self.step(evs[k])
+            torch.cuda.synchronize()
+            gd.barrier()
+            return gd.max_over_ranks(time.perf_counter() - t0, dev), evs
+
+        def verify(self):
+            """correctness of what was just timed: EVERY frame decodes to its payload, every sync offset exact,
+            and (N>1) every rank holds every rank's bits in the documented block-cyclic order"""
+            x = torch.bitwise_xor(self.bits, payload)
+            bit_errors = int(torch.count_nonzero(x).item())      # differing bytes (0 => BER 0)
+            if bit_errors:
+                bit_errors = int(np.unpackbits(x.cpu().numpy()).sum())
+            sync_ok = bool(torch.equal(self.starts_all, exp_starts))
+            gather_ok = None
+            if multi:
+                import torch.distributed as tdist
+                mine = gd.cyclic_frame_index(rank, world, F, self.chunks).to(dev)
+                gather_ok = bool(torch.equal(self.gathered[mine], self.bits))
+                # ... and this rank's copy of every OTHER rank's rows matches what that rank decoded (a checksum of
+                # each rank's rows, weighted by row number, is exchanged and recomputed on the local copy)
+                w = (torch.arange(F, device=dev, dtype=torch.int64) % 65521 + 1)[:, None]
+
+                def checksum(rows):
+                    return (rows.to(torch.int64) * w).sum()
+                sums = torch.zeros(world, dtype=torch.int64, device=dev)
+                sums[rank] = checksum(self.bits)
+                tdist.all_reduce(sums, op=tdist.ReduceOp.SUM)
+                for r in range(world):
+                    idx = gd.cyclic_frame_index(r, world, F, self.chunks).to(dev)
+                    gather_ok = gather_ok and bool(checksum(self.gathered[idx]) == sums[r])
+                flag = torch.tensor([1.0 if gather_ok else 0.0, float(bit_errors == 0), float(sync_ok)], dtype=torch.float64, device=dev)
+                tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)           # every rank's verdict, not rank 0's alone
+                gather_ok = bool(flag[0].item() == 1.0)
+                if flag[1].item() != 1.0 and bit_errors == 0:
+                    bit_errors = -1                                       # some other rank saw bit errors
+                sync_ok = bool(flag[2].item() == 1.0)
+            return bit_errors, sync_ok, gather_ok
+
+    run = Run(args.chunks)
+    dt, evs = run.timed(args.warmup, args.steps)
+    bit_errors, sync_ok, gather_ok = run.verify()
+    chunks, Fc = run.chunks, run.Fc
+    step = run.step
+
+    # N>1: the same batch once more with the literal single all-gather of the north_star (one collective per step,
+    # issued after the kernels, nothing overlapped), reported beside the chunked result
+    single = None
+    if multi and run.chunks != 1:
+        del run.gathered, run.og
+        run1 = Run(1)
+        dt1, _ = run1.timed(min(args.warmup, 2), args.steps)
+        be1, so1, go1 = run1.verify()
+        single = {"chunks": 1, "ms_per_step": dt1 / args.steps * 1e3, "value": world * n_samples * args.steps / dt1,
+                  "unit": "samples/s", "bit_errors": be1, "sync_exact": so1, "gather_exact": go1}
+        del run1
 
     # sustained package power: the same step repeated for ~2 s after the timed region (the hwmon sensor averages
     # over a window far longer than a 20-step run), median of the second half of the samples
@@ -337,20 +475,39 @@ def main():
         except Exception:
             traffic = None
 
+    extra = {}
+    if world == 1 and not multi:
+        del run.bits
+        if not args.no_config5:
+            extra.update(config5_rooflines(dev))
+        if not args.no_stream:
+            extra.update(stream_sync_roofline(dev))
+
     if rank == 0:
+        from gf3_audio_modem_amd import _lib
+        ver, src = _lib.build_id()
+        total_frames = F * world
+        if multi and world > 1:
+            workload = (f"BASELINE config 4: {total_frames} frames of the config-2 geometry (N=4096 CP=512 P=2 D=8 QPSK, "
+                        f"chirp-prefixed frame buffers) sharded {F} per GPU, windowed chirp sync + LS pilot equalisation + "
+                        f"hard demap, RCCL all-gather of the packed decoded bits" + (" (1 048 576 frames at 8 GPUs)" if F == 131072 else ""))
+        else:
+            workload = ("BASELINE config 2: N=4096 CP=512 P=2 D=8 QPSK, chirp-prefixed frame buffers, "
+                        "windowed chirp sync + LS pilot equalisation + hard demap")
         out = {
             "metric": "demod samples/sec + decoded-bit BER vs OFDM.py, N=4096 QPSK, 1/2/4/8 GPU",
             "value": world * n_samples * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: N=4096 CP=512 P=2 D=8 QPSK, chirp-prefixed frame buffers, "
-                                   "windowed chirp sync + LS pilot equalisation + hard demap",
-                       "frames_per_gpu": F, "samples_per_frame": args.stride, "sample_storage": "f32",
+            "config": {"workload": workload,
+                       "frames_per_gpu": F, "frames_total": total_frames, "samples_per_frame": args.stride, "sample_storage": "f32",
                        "sync_window_lags": args.window, "parallelism": f"frames sharded over {world} GPU(s), "
                        f"packed bits all-gathered in {chunks} chunk(s) under compute" if multi else "single GPU"},
-            "ber": bit_errors / (F * cfg.bits_per_frame), "bit_errors": bit_errors, "frames_checked": F, "sync_exact": sync_ok,
-            "gather_exact": gather_ok,
+            "ber": bit_errors / (F * cfg.bits_per_frame), "bit_errors": bit_errors, "frames_checked": F * world if multi else F, "sync_exact": sync_ok,
+            "gather_exact": gather_ok, "ranks_in_group": (torch.distributed.get_world_size() if multi else 1),
+            "single_gather": single,
+            "library": {"version": ver, "source_sha16": src},
             "roofline": {"kernel": "demod_kernel<2048,f32,MODE_QPSK>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_demod, "avg_launch_ms": t_demod * 1e3,
@@ -362,6 +519,7 @@ def main():
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_sync / t_sync / 1e9 / HBM_PEAK_GBS,
                               "algorithmic_bytes_per_launch": bytes_sync, "avg_launch_ms": t_sync * 1e3},
         }
+        out.update(extra)
         if world == 1 and not multi and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg, big, payload, args.window, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -132,30 +132,41 @@ class transmitter(CamG):
     def encode(self, bits):
         if self.encoding == "LDPC":
             raise NotImplementedError("LDPC encoding is out of scope (pyldpc; marked broken in the reference, OFDM.py:21)")
-        if self.encoding == "XOR":                                     # OFDM.py:163-173
-            known_bits = np.tile(self.known_sequence[:self.data_bits_per_symbol],
-                                 int(np.ceil(len(bits) / self.data_bits_per_symbol)))[:len(bits)]
-            bits = np.bitwise_xor(bits, known_bits)
-        bits_per_packet = self.data_bits_per_symbol * self.packet_length
-        padding_length = (bits_per_packet - len(bits) % bits_per_packet) % bits_per_packet
-        padding = np.random.binomial(n=1, p=0.5, size=(padding_length,))   # "packing with zeros is bad"
-        return np.hstack([bits, padding])
+        bits = np.asarray(bits)
+        if self.encoding == "XOR":                                     # whitening, OFDM.py:163-166
+            mask = np.resize(np.asarray(self.known_sequence[:self.data_bits_per_symbol]), bits.shape)
+            bits = bits ^ mask.astype(bits.dtype)
+        # fill the last packet with coin flips (OFDM.py:168-173, 178-185): ONE draw from the legacy global RNG, of
+        # exactly the missing length, so a seeded run consumes the generator as the reference does
+        per_packet = self.packet_length * self.data_bits_per_symbol
+        missing = -len(bits) % per_packet
+        return np.concatenate([bits, np.random.binomial(n=1, p=0.5, size=(missing,))])
 
     def SP(self, bits):
         return bits.reshape(-1, self.data_carriers_per_symbol, self.mu)
 
     def random_qpsk(self):
-        qpsk = np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2)
-        return np.random.choice(qpsk, size=(self.K - self.data_carriers_per_symbol), replace=True)
+        """Filler for the carriers outside the data band (OFDM.py:201-203): one np.random.choice over the four
+        unit-energy corners in the order ++, +-, -+, -- (the order decides which corner a drawn index means)."""
+        corners = np.array([complex(re, im) for re in (1, -1) for im in (1, -1)]) / np.sqrt(2)
+        return np.random.choice(corners, size=(self.K - self.data_carriers_per_symbol), replace=True)
+
+    def _half_spectrum(self, payload, filler):
+        """[n, K] values of carriers 1..K: payload on the data carriers, `filler` (one vector, shared by every
+        symbol) on the rest."""
+        half = np.empty((payload.shape[0], self.K), dtype=complex)
+        half[:, np.asarray(self.data_carriers) - 1] = payload
+        half[:, np.asarray(self.unused_carriers) - 1] = filler
+        return half
 
     def build_OFDM_symbol(self, payload):
-        symbols = np.zeros([payload.shape[0], self.ofdm_symbol_size], dtype=complex)
-        rand_qpsk = self.random_qpsk()
-        symbols[:, self.data_carriers] = payload
-        symbols[:, self.unused_carriers] = rand_qpsk
-        symbols[:, -self.data_carriers] = np.conj(payload)
-        symbols[:, -self.unused_carriers] = np.conj(rand_qpsk)
-        return symbols
+        """OFDM.py:207-217 as a half spectrum and its mirror image: bins 1..K carry the symbols, bins N-K..N-1
+        their conjugates in reverse order, DC and Nyquist stay zero (gf3_tx_frames fills its spectra the same way)."""
+        half = self._half_spectrum(payload, self.random_qpsk())
+        full = np.zeros((payload.shape[0], self.ofdm_symbol_size), dtype=complex)
+        full[:, 1:self.K + 1] = half
+        full[:, self.ofdm_symbol_size - self.K:] = np.conj(half[:, ::-1])
+        return full
 
     def add_cp(self, time_data):
         if self.cp_length == 0:
@@ -165,10 +176,14 @@ class transmitter(CamG):
     def build_schmidlcox(self):
         """OFDM.py:230-238: known symbols on every other carrier.  (K = N/2-1 is odd, so the slice assignment
         raises ValueError exactly as the reference's does; kept for surface parity -- the standard moved to chirps.)"""
-        symbols = self.map(self.SP(self.known_sequence))
-        p = np.zeros(self.K, dtype=complex)
-        p[::2] = symbols[0, :self.K // 2]
-        return p.reshape(-1, self.K)
+        first = self.map(self.SP(self.known_sequence))[0]
+        slots = np.arange(0, self.K, 2)                                 # every other carrier
+        values = first[:self.K // 2]
+        if values.shape != slots.shape:
+            raise ValueError(f"could not broadcast input array from shape {values.shape} into shape {slots.shape}")
+        row = np.zeros((1, self.K), dtype=complex)
+        row[0, slots] = values
+        return row
 
     def send_to_stream(self, time_data, sync):
         """OFDM.py:242-275: frame time-domain symbols (CP already added) into
@@ -286,10 +301,12 @@ class receiver(transmitter):
         return full.reshape(F, M, N).cpu().numpy()
 
     def get_data(self, OFDM_symbols):
-        start_pilots = OFDM_symbols[:, :self.no_pilots, self.carriers]
-        end_pilots = OFDM_symbols[:, -self.no_pilots:, self.carriers]
-        data_symbols = OFDM_symbols[:, self.no_pilots:-self.no_pilots, self.carriers]
-        return data_symbols, start_pilots, end_pilots
+        """OFDM.py:412-418: carriers 1..K of every symbol, cut along the symbol axis into
+        [P start pilots | D data | P end pilots]; returned in the reference's order (data, start, end)."""
+        P = self.no_pilots
+        active = np.take(OFDM_symbols, self.carriers, axis=2)
+        start, data, end = np.split(active, [P, active.shape[1] - P], axis=1)
+        return data, start, end
 
     # ---- equalise (OFDM.py:422-480) ---------------------------------------------
     def equalise(self, data_symbols, start_pilots, end_pilots):
@@ -395,11 +412,9 @@ class receiver(transmitter):
 # ---- file framing (OFDM.py:756-794): host I/O only -------------------------------------------------
 def load_file(file_name):
     """name\\0size\\0 header + file bytes -> bit array (OFDM.py:756-761)."""
-    data_bytes = np.fromfile("input_files/" + file_name, dtype=np.uint8)
-    file_info = file_name + "\x00" + str(len(data_bytes)) + "\x00"
-    b = bytearray()
-    b.extend(map(ord, file_info))
-    return np.unpackbits(np.hstack([b, data_bytes]))
+    body = np.fromfile(os.path.join("input_files", file_name), dtype=np.uint8)
+    header = f"{file_name}\0{body.size}\0".encode("latin-1")         # one byte per character, as ord() gives
+    return np.unpackbits(np.concatenate([np.frombuffer(header, dtype=np.uint8), body]))
 
 
 def save_file(rx_bits):
@@ -415,5 +430,6 @@ def save_file(rx_bits):
     print("File Name: " + file_name + "\nFile Size: " + file_size + " bytes")
     data = data[:int(file_size)]
     os.makedirs("output_files", exist_ok=True)
-    data.tofile("output_files/" + file_name[:-4] + "_received" + file_name[-4:])
+    stem, ext = file_name[:-4], file_name[-4:]                        # the reference assumes a 3-letter extension
+    data.tofile(os.path.join("output_files", f"{stem}_received{ext}"))
     return file_name, data

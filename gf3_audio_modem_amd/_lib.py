@@ -63,13 +63,17 @@ def load():
     if _lib is not None:
         return _lib
     path = lib_path()
-    if not os.path.exists(path):
-        # not built yet: compile it here if the ROCm toolchain is present (same gfx950 build as
-        # __graft_entry__.build()); otherwise fail loudly -- there is no other implementation to fall back to
-        import shutil
-        from . import build as _build
-        if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+    from . import build as _build
+    if not os.environ.get("GF3_LIB") and _build.stale():
+        # missing, or older than gf3rx.hip / gf3rx_device.h / gf3rx.h (content hash): compile it here if the ROCm
+        # toolchain is present (same gfx950 build as __graft_entry__.build(), temp file + rename under a lock);
+        # otherwise fail loudly -- kernels that do not match the source must not run, and there is no other
+        # implementation to fall back to
+        if _build.have_compiler():
             _build.build_lib()
+        elif os.path.exists(path):
+            raise ImportError(f"{path} does not match its sources (hash {_build.built_hash()} != {_build.source_hash()}) "
+                              "and no hipcc is available to rebuild it")
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is not built. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -81,3 +85,10 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def build_id():
+    """(library version string, first 16 hex digits of the source hash it was built from) for bench records."""
+    from . import build as _build
+    lib = load()
+    return lib.gf3_version().decode(), (_build.built_hash() or "unknown")[:16]

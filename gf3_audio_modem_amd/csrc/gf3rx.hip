@@ -42,6 +42,7 @@ struct DemodArgs {
     const cplx* inv_known;    // [K] 1/known symbol
     const int* pos;           // [K] data-carrier position or -1
     int contig_lo;            // >0: data bins are contig_lo .. contig_lo+C-1 in order (no table look-up)
+    int ring;                 // symbols held by the decision-byte ring in LDS (power of two, see demod_ring)
     const double* cre; const double* cim; const int* clab;   // [M]
     int fit_lo, fit_hi;       // effective python-slice bounds, fit_hi <= K
     double xbar, inv_sxx;
@@ -119,19 +120,8 @@ __global__ __launch_bounds__(NC / 8, Occ<NC>::WPS) void rfft_kernel(RfftArgs a) 
 // start pilots -> end pilots -> data, the next symbol's raw samples being fetched
 // while the current one is transformed.
 // ============================================================================
-// literal argmin scan over the reference QPSK table (+q,+q) (+q,-q) (-q,-q) (-q,+q) with
-// labels 00 10 11 01 (OFDM.py:72-77, 493-496); first minimum wins, branch-free
-GF3_DEV uint32_t qpsk_scan(cplx e, double q) {
-    const double xp = (e.x - q) * (e.x - q), xm = (e.x + q) * (e.x + q);
-    const double yp = (e.y - q) * (e.y - q), ym = (e.y + q) * (e.y + q);
-    double bd = xp + yp; uint32_t lab = 0u;
-    double d = xp + ym; if (d < bd) { bd = d; lab = 2u; }
-    d = xm + ym;        if (d < bd) { bd = d; lab = 3u; }
-    d = xm + yp;        if (d < bd) { bd = d; lab = 1u; }
-    return lab;
-}
-
-// Decision of the literal scan above for exact arithmetic, from the signs of e (or of any
+// Decision of the reference's argmin over its QPSK table (+q,+q) (+q,-q) (-q,-q) (-q,+q) with labels 00 10 11 01
+// (OFDM.py:72-77, 493-496; first minimum wins) for exact arithmetic, from the signs of e (or of any
 // positive multiple of e): the scan's first-minimum rule breaks the four axis ties as
 // Re=0 -> Re>=0 side, Im=0 -> (Re<0 ? Im<0 side : Im>=0 side); NaN/Inf -> first point.
 GF3_DEV uint32_t qpsk_sign_rule(cplx e) {
@@ -166,7 +156,11 @@ GF3_DEV int sep_axis(double x, const double* lv, int n, bool& clear) {
     clear = (d1 - d0) > 1e-9 * (d1 + d0);       // false also for NaN / Inf inputs
     return best;
 }
-// literal first-minimum scan over the whole table (OFDM.py:493-496)
+// First-minimum scan over the whole table, deciding as `argmin(abs(sym - table))` does (OFDM.py:490-496).
+// Squared distances order the points exactly as the reference's distances do unless two of them agree to within
+// rounding; then (margin 1e-12 relative, four orders above the rounding of either form) the contenders are
+// re-measured with the reference's own |.| (np_cabs, bit-identical) in table order and the first minimum wins --
+// which also covers exact mid-points, where different squared distances round to the SAME |.|.
 GF3_DEV int scan_table(cplx e, const double* cre, const double* cim, int M) {
     int best = 0;
     double dx = e.x - cre[0], dy = e.y - cim[0];
@@ -175,6 +169,24 @@ GF3_DEV int scan_table(cplx e, const double* cre, const double* cim, int M) {
         dx = e.x - cre[c]; dy = e.y - cim[c];
         const double d = dx * dx + dy * dy;
         if (d < bd) { bd = d; best = c; }
+    }
+    const double lim = bd * (1.0 + 1e-12);             // (NaN: every comparison false -> point 0, as argmin gives)
+    bool tie = false;
+    for (int c = 0; c < M; ++c) {
+        dx = e.x - cre[c]; dy = e.y - cim[c];
+        tie = tie || (c != best && dx * dx + dy * dy <= lim);
+    }
+    if (tie) {
+        double hb = INFINITY;
+        best = -1;
+        for (int c = 0; c < M; ++c) {
+            dx = e.x - cre[c]; dy = e.y - cim[c];
+            if (dx * dx + dy * dy <= lim) {
+                const double h = np_cabs(dx, dy);
+                if (best < 0 || h < hb) { hb = h; best = c; }
+            }
+        }
+        if (best < 0) best = 0;
     }
     return best;
 }
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     double* scratch = (double*)smem;
     cplx* rtab = (cplx*)(scratch + 32);                                   // [2][64 + NC/64 + 1]
     cplx* lds = rtab + 2 * (64 + NC / 64 + 1);                            // FFT buffer, DemodOcc::LDS_ELEMS points
-    uint8_t* labs = (uint8_t*)(lds + DemodOcc<NC, MODE>::LDS_ELEMS);      // [2][C] decisions, one byte each
+    uint8_t* labs = (uint8_t*)(lds + DemodOcc<NC, MODE>::LDS_ELEMS);      // [ring][C] decisions, one byte each
     const int tid = threadIdx.x;
     const int64_t f = blockIdx.x;
     const int K = a.K, P = a.P, D = a.D, S = a.S;
@@ -385,10 +397,14 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     GF3_STAMP(3);
 
     // ---- data symbols: FFT -> /Hest -> demap -> bit-pack (OFDM.py:466-478, 487-505)
-    // Decisions are staged as one byte per data carrier in a two-symbol LDS ring and
+    // Decisions are staged as one byte per data carrier in a ring of `ring` symbols in LDS and
     // packed into output words one symbol later (after the next FFT's barriers), so the
-    // packing needs no atomics and no barrier of its own.
+    // packing needs no atomics and no barrier of its own.  While symbol l is being decided, the words
+    // completed by symbol l-1 are packed; the first of them starts up to 31 bits before that symbol, i.e.
+    // ceil(32 / (C mu)) symbols back, and none of those slots may be the one symbol l is written to:
+    // ring >= ceil(32 / (C mu)) + 2 (rounded up to a power of two on the host, demod_ring).
     const int C = a.C, mu = a.mu;
+    const int RC = a.ring * C;
     auto pack_words = [&](int l, bool tail) {
         const int wlo = (l * Bs) >> 5, whi = ((l + 1) * Bs) >> 5;
         const int nlab = D * C;                                            // labels in the packet
@@ -397,14 +413,14 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
             // the four 2-bit labels of a dword into a byte (label i -> bits 7-2i of it)
             for (int w = wlo + launder(tid); w < whi + (tail ? 1 : 0); w += T) {
                 const int i0 = 16 * w;
-                int r = i0 % (2 * C);
+                int r = i0 % RC;
                 uint32_t x = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint32_t d4 = (i0 + 4 * j < nlab) ? *(const uint32_t*)(labs + r) : 0u;
                     if (i0 + 4 * j + 4 > nlab) d4 &= 0xffffffffu >> (8 * (i0 + 4 * j + 4 - nlab));   // C even => whole pairs
                     x = (x << 8) | ((d4 * 0x40100401u) >> 24);
-                    r += 4; if (r >= 2 * C) r -= 2 * C;
+                    r += 4; if (r >= RC) r -= RC;
                 }
                 if (w < whi) {
                     if ((a.row_bytes & 3) == 0) ((uint32_t*)row)[w] = __builtin_bswap32(x);
@@ -419,14 +435,14 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         for (int w = wlo + launder(tid); w < whi + (tail ? 1 : 0); w += T) {
             int i = (32 * w) / mu;                                         // first label touching the word
             const int skip = 32 * w - i * mu;
-            int r = i % (2 * C);
+            int r = i % RC;
             uint64_t acc = 0;
             int nb = 0;
             while (nb < skip + 32) {
                 const uint32_t lb = (i < nlab) ? labs[r] : 0u;
                 acc = (acc << mu) | lb;
                 nb += mu; ++i;
-                if (++r == 2 * C) r = 0;
+                if (++r == RC) r = 0;
             }
             const uint32_t x = (uint32_t)(acc >> (nb - skip - 32));
             if (w < whi) {
@@ -439,7 +455,6 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         }
     };
     const double denom = (double)(D + P);
-    const double qq = a.qpsk_q;
     // Channel-model phasor per carrier: Hest = mag * g_l,  g_l = u exp(j slope n f_l),  f_l = (l + P/2)/(D+P)
     // is linear in l, so g_{l+1} = g_l * exp(j slope n / (D+P)): one complex multiply per carrier per symbol
     // and no sin/cos inside the symbol loop.  The two start-up rotations exp(j phi0 n), exp(j dphi n) come
@@ -475,7 +490,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         else transform(2 * P + l);
         if (l > 0) pack_words(l - 1, false);
         const double fl = ((double)l + 0.5 * (double)P) / denom;          // (l + P/2)/(D+P)
-        uint8_t* lab_l = labs + (l & 1) * C;
+        uint8_t* lab_l = labs + (l & (a.ring - 1)) * C;
         if constexpr (MODE == MODE_QPSK) {
             // all eight carriers in one straight line: rotate, advance the phasors, take the sign bits; the exact
             // tie / NaN / Inf rule is one rarely taken branch for the whole group instead of one per carrier
@@ -518,10 +533,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
                     if (ps >= 0 && a.eq) a.eq[((int64_t)f * D + l) * C + ps] = e;
                 }
                 if (ps >= 0) {
-                    uint32_t lab;
-                    if (qq > 0.0) lab = qpsk_scan(e, qq);
-                    else lab = decide_label(e, a.sep, a.cre, a.cim, a.clab, a.M);
-                    lab_l[ps] = (uint8_t)lab;
+                    lab_l[ps] = (uint8_t)decide_label(e, a.sep, a.cre, a.cim, a.clab, a.M);
                 }
             }
         }
@@ -1209,12 +1221,38 @@ struct gf3_ctx {
     SepTab sep{};
     unsigned long long* stamps = nullptr;
     int contig_lo = 0;
+    int device = 0;                     // HIP device the context (tables, plans) lives on
     std::vector<double> chirp;
     std::vector<cplx> known_pts;
     mutable char err[512];
 };
 
-static char g_err[512] = "";
+// message of a failure that has no context to carry it (gf3_ctx_create, null ctx): one buffer per calling thread,
+// so concurrent callers on different host threads do not overwrite each other's text
+static thread_local char g_err[512] = "";
+
+// Scratch device allocations of the set-up helpers: released on every return path.
+struct DevTmp {
+    std::vector<void*> p;
+    ~DevTmp() { for (void* q : p) if (q) (void)hipFree(q); }
+    template <typename T> hipError_t alloc(T** out, size_t n) {
+        hipError_t e = hipMalloc((void**)out, n * sizeof(T));
+        if (e == hipSuccess) p.push_back((void*)*out);
+        return e;
+    }
+    template <typename T> hipError_t put(T** out, const T* h, size_t n) {
+        hipError_t e = alloc(out, n);
+        return e != hipSuccess ? e : hipMemcpy(*out, h, n * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+// Every entry point that launches work runs on the context's device, whatever device the calling thread had
+// current (kernels, copies and frees of a context created on cuda:1 must not land on cuda:0's streams).
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(const gf3_ctx* c);
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 
 static int fail(const gf3_ctx* c, int code, const char* fmt, ...) {
     va_list ap;
@@ -1227,6 +1265,11 @@ static int fail(const gf3_ctx* c, int code, const char* fmt, ...) {
 }
 #define HIPCHK(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     return fail(c, GF3_EHIP, "%s failed: %s", #x, hipGetErrorString(e_)); } while (0)
+
+DeviceGuard::DeviceGuard(const gf3_ctx* c) {
+    if (!c) return;
+    if (hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+}
 
 template <typename T> static hipError_t upload(T** dptr, const T* h, size_t n) {
     hipError_t e = hipMalloc((void**)dptr, n * sizeof(T));
@@ -1307,12 +1350,12 @@ static int build_plan(gf3_ctx* c, CorrPlan* pl, int NCp, FftTables t, int Lp_max
     std::vector<int64_t> off(Q);
     for (int q = 0; q < Q; ++q) off[q] = (int64_t)q * N;
     double* d_h = nullptr; int64_t* d_off = nullptr;
-    HIPCHK(c, upload(&d_h, h.data(), h.size()));
-    HIPCHK(c, upload(&d_off, off.data(), off.size()));
-    HIPCHK(c, hipMalloc((void**)&pl->d_Hq, (size_t)Q * (NCp + 1) * sizeof(cplx)));
+    DevTmp tmp;                                        // frees d_h, d_off on every path out of here
+    HIPCHK(c, tmp.put(&d_h, h.data(), h.size()));
+    HIPCHK(c, tmp.put(&d_off, off.data(), off.size()));
+    HIPCHK(c, hipMalloc((void**)&pl->d_Hq, (size_t)Q * (NCp + 1) * sizeof(cplx)));     // owned by the plan (gf3_ctx_destroy)
     HIPCHK(c, run_rfft_nc(NCp, t, d_h, (int64_t)h.size(), DT_F64, d_off, Q, pl->d_Hq, 0));
     HIPCHK(c, hipStreamSynchronize(0));
-    (void)hipFree(d_h); (void)hipFree(d_off);
     return GF3_OK;
 }
 
@@ -1337,6 +1380,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     gf3_ctx* c = new gf3_ctx();
     c->cfg = *cfg;
     c->err[0] = 0;
+    if (hipGetDevice(&c->device) != hipSuccess) { delete c; return fail(nullptr, GF3_EHIP, "hipGetDevice failed: no usable GPU"); }
     c->NC = N / 2; c->K = N / 2 - 1; c->S = N + cfg->CP;
     c->Lc = cfg->Lc > 0 ? cfg->Lc : 5 * c->S;
     const int K = c->K;
@@ -1490,6 +1534,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
 
 extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
     if (!c) return;
+    DeviceGuard dg(c);
     void* ptrs[] = {c->d_tw_x[0], c->d_twn_x[0], c->d_tw_x[1], c->d_twn_x[1], c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
                     c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_known_time};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1510,16 +1555,26 @@ extern "C" int gf3_chirp_replica(const gf3_ctx* c, double* h_out) {
 
 extern "C" int gf3_rfft_batch(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_offsets, int64_t n_sym,
                               void* d_out, void* stream) {
+    DeviceGuard dg(c);
     if (c && n_sym == 0) return GF3_OK;
     if (!c || !d_in || !d_offsets || !d_out || n_sym < 0) return fail(c, GF3_EINVAL, "gf3_rfft_batch: bad argument");
     HIPCHK(c, run_rfft(c, d_in, n_in, c->cfg.in_dtype, d_offsets, n_sym, (cplx*)d_out, (hipStream_t)stream));
     return GF3_OK;
 }
 
+// symbols in the decision-byte ring of demod_kernel: ceil(32 / (C mu)) + 2, rounded up to a power of two
+// (>= 4: the QPSK packer reads the ring one aligned dword at a time, so ring * C must be a multiple of 4)
+static int demod_ring(const gf3_ctx* c) {
+    const int Bs = c->cfg.C * c->cfg.mu;
+    const int need = (32 + Bs - 1) / Bs + 2;
+    int r = 4;
+    while (r < need) r <<= 1;
+    return r;
+}
 static size_t demod_lds_bytes(const gf3_ctx* c, bool lean = false) {
     const bool inplace = lean && GF3_DEMOD_WPS > 2 && c->NC <= 2048;
     const size_t fft = inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC);
-    const size_t tail = fft + (size_t)((2 * c->cfg.C + 15) & ~15);              // FFT buffer + decision bytes ...
+    const size_t tail = fft + (size_t)((demod_ring(c) * c->cfg.C + 15) & ~15);  // FFT buffer + decision bytes ...
     const size_t fit = (size_t)2 * (c->fit_hi - c->fit_lo) * sizeof(cplx);      // ... overlaid by Hs, He of the fit range
     return 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) + (fit > tail ? fit : tail);
 }
@@ -1527,12 +1582,13 @@ static size_t demod_lds_bytes(const gf3_ctx* c, bool lean = false) {
 extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,
                                 uint8_t* d_bits, void* d_eq, void* d_Hs, void* d_He, double* d_slope, void* d_Hest,
                                 int32_t* d_status, void* stream) {
+    DeviceGuard dg(c);
     if (c && F == 0) return GF3_OK;
     if (!c || !d_in || !d_off || !d_bits || F < 0) return fail(c, GF3_EINVAL, "gf3_demod_frames: bad argument");
     const gf3_config& g = c->cfg;
     DemodArgs a{{c->d_tw, c->d_twn}, d_in, n_in, d_off, g.in_dtype,
                 g.CP, c->S, g.P, g.D, c->K, g.C, g.mu, g.M,
-                c->d_known, c->d_pos, c->contig_lo, c->d_cre, c->d_cim, c->d_clab,
+                c->d_known, c->d_pos, c->contig_lo, demod_ring(c), c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, (cplx*)d_eq, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, d_status,
                 nullptr, nullptr, nullptr, nullptr, c->qpsk_q, c->sep, c->stamps};
@@ -1551,12 +1607,13 @@ extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, cons
 extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start, const void* d_end, int64_t F,
                             void* d_eq_all, void* d_Hs, void* d_He, double* d_slope, void* d_Hest,
                             uint8_t* d_bits, void* stream) {
+    DeviceGuard dg(c);
     if (c && F == 0) return GF3_OK;
     if (!c || !d_data || !d_start || !d_end || !d_bits || F < 0) return fail(c, GF3_EINVAL, "gf3_equalise: bad argument");
     const gf3_config& g = c->cfg;
     DemodArgs a{{c->d_tw, c->d_twn}, nullptr, 0, nullptr, g.in_dtype,
                 g.CP, c->S, g.P, g.D, c->K, g.C, g.mu, g.M,
-                c->d_known, c->d_pos, c->contig_lo, c->d_cre, c->d_cim, c->d_clab,
+                c->d_known, c->d_pos, c->contig_lo, demod_ring(c), c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, nullptr, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, nullptr,
                 (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_q, c->sep, nullptr};
@@ -1602,11 +1659,12 @@ static int build_known_time(gf3_ctx* c) {
     cplx* d_kn = nullptr; double* d_row = nullptr; int* d_nopos = nullptr; uint8_t* d_nobits = nullptr;
     std::vector<int> nopos(c->K, -1);
     const int64_t rowlen = c->Lc + c->S;
-    HIPCHK(c, upload(&d_kn, c->known_pts.data(), c->known_pts.size()));
-    HIPCHK(c, upload(&d_nopos, nopos.data(), nopos.size()));
-    HIPCHK(c, hipMalloc((void**)&d_row, rowlen * sizeof(double)));
-    HIPCHK(c, hipMalloc((void**)&d_nobits, 16));
-    HIPCHK(c, hipMalloc((void**)&c->d_known_time, c->S * sizeof(double)));
+    DevTmp tmp;                                        // frees the four scratch buffers on every path out of here
+    HIPCHK(c, tmp.put(&d_kn, c->known_pts.data(), c->known_pts.size()));
+    HIPCHK(c, tmp.put(&d_nopos, nopos.data(), nopos.size()));
+    HIPCHK(c, tmp.alloc(&d_row, (size_t)rowlen));
+    HIPCHK(c, tmp.alloc(&d_nobits, (size_t)16));
+    HIPCHK(c, hipMalloc((void**)&c->d_known_time, c->S * sizeof(double)));                // owned by the context
     HIPCHK(c, hipMemset(c->d_known_time, 0, c->S * sizeof(double)));
     a.P = 0; a.D = 1; a.C = 0; a.pos = d_nopos; a.contig_lo = 0; a.filler = d_kn; a.known_time = c->d_known_time;
     a.bits = d_nobits; a.row_bytes = 0; a.gaps = nullptr; a.out = d_row; a.stride = rowlen; a.out_dt = DT_F64;
@@ -1617,12 +1675,12 @@ static int build_known_time(gf3_ctx* c) {
     HIPCHK(c, hipMemcpy(h.data(), d_row + c->Lc, c->S * sizeof(double), hipMemcpyDeviceToHost));
     for (auto& x : h) x *= 0.5;                          // stored before the x2 gain
     HIPCHK(c, hipMemcpy(c->d_known_time, h.data(), c->S * sizeof(double), hipMemcpyHostToDevice));
-    (void)hipFree(d_kn); (void)hipFree(d_row); (void)hipFree(d_nopos); (void)hipFree(d_nobits);
     return GF3_OK;
 }
 
 extern "C" int gf3_tx_frames(gf3_ctx* c, const uint8_t* d_bits_packed, const void* d_filler_c128, const int64_t* d_gaps,
                              int64_t F, void* d_out, int64_t stride, int32_t out_dtype, void* stream) {
+    DeviceGuard dg(c);
     if (c && F == 0) return GF3_OK;
     if (!c || !d_bits_packed || !d_filler_c128 || !d_out || F < 0 || (out_dtype != GF3_F32 && out_dtype != GF3_F64))
         return fail(c, GF3_EINVAL, "gf3_tx_frames: bad argument");
@@ -1706,6 +1764,7 @@ __global__ __launch_bounds__(1024) void schmidl_cox_kernel(ScArgs a) {
 }
 
 extern "C" int gf3_schmidl_cox(gf3_ctx* c, const void* d_r, int64_t n, int64_t search_len, int64_t* d_index, void* stream) {
+    DeviceGuard dg(c);
     if (!c || !d_r || !d_index || search_len < 2) return fail(c, GF3_EINVAL, "gf3_schmidl_cox: bad argument");
     const int L = c->K + 1;
     if (n < search_len - 1 + 2 * (int64_t)L) return fail(c, GF3_EINVAL, "gf3_schmidl_cox: stream shorter than search length + 2L");
@@ -1731,6 +1790,7 @@ static hipError_t run_corr(const gf3_ctx* c, const CorrPlan& pl, const CorrArgs&
 
 extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64_t F, int64_t stride,
                                int32_t win_lo, int32_t win_hi, int64_t* d_starts, double* d_peak, void* stream) {
+    DeviceGuard dg(c);
     if (c && F == 0) return GF3_OK;
     if (!c || !d_in || !d_starts || F < 0) return fail(c, GF3_EINVAL, "gf3_sync_frames: bad argument");
     const int W = win_hi - win_lo;
@@ -1758,8 +1818,10 @@ static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
     w.o_part = take((size_t)w.nb_max * 8);
     w.o_cnt = take((size_t)w.nb_c * 8);
     w.o_off = take((size_t)w.nb_c * 8);
-    w.o_cand = take((size_t)(w.nz / 2 + 2) * 8);
-    w.o_misc = take(64);
+    w.o_misc = take(64);                                 // (ahead of the lists: nothing that grows can reach it)
+    // Every lag can be a candidate: the rule admits minima and flat runs, so a constant or DC-biased stream
+    // (u8 silence at 128) puts rounding-noise extrema above the threshold on nearly all lags of the overlap.
+    w.o_cand = take((size_t)(w.nz + 2) * 8);
     w.nblk = (w.plen + c->stream_plan.Lp - 1) / c->stream_plan.Lp;
     w.nwin = w.nblk + c->stream_plan.Q - 1;
     w.o_spec = take((size_t)w.nwin * (c->stream_plan.NC + 1) * sizeof(cplx));
@@ -1773,6 +1835,7 @@ extern "C" int64_t gf3_sync_stream_workspace_bytes(const gf3_ctx* c, int64_t n) 
 
 extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* d_peaks, int64_t cap,
                                int64_t* n_peaks, void* d_work, double* d_corr, void* stream) {
+    DeviceGuard dg(c);
     if (!c || !d_r || !d_peaks || !n_peaks || !d_work || n < 3 || cap < 1)
         return fail(c, GF3_EINVAL, "gf3_sync_stream: bad argument");
     hipStream_t st = (hipStream_t)stream;
@@ -1845,11 +1908,13 @@ static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, ui
     return GF3_OK;
 }
 extern "C" int gf3_demap_hard(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* d_bits, uint8_t* d_idx, void* stream) {
+    DeviceGuard dg(c);
     if (c && n == 0) return GF3_OK;
     if (!c || !d_sym || !d_bits || n < 0) return fail(c, GF3_EINVAL, "gf3_demap_hard: bad argument");
     return run_demap(c, d_sym, n, d_bits, d_idx, nullptr, 1.0, stream);
 }
 extern "C" int gf3_soft_demap(gf3_ctx* c, const void* d_sym, int64_t n, double noise_var, float* d_llr, void* stream) {
+    DeviceGuard dg(c);
     if (c && n == 0) return GF3_OK;
     if (!c || !d_sym || !d_llr || n < 0 || !(noise_var > 0)) return fail(c, GF3_EINVAL, "gf3_soft_demap: bad argument");
     return run_demap(c, d_sym, n, nullptr, nullptr, d_llr, noise_var, stream);

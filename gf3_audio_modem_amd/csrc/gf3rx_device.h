@@ -41,6 +41,26 @@ GF3_DEV cplx cdiv_np(cplx a, cplx b) {
     return cmk((a.x * rat + a.y) * scl, (a.y * rat - a.x) * scl);
 }
 
+// |x + iy| the way NumPy's complex128 `absolute` loop computes it (the reference's `abs(symbols - constellation)`,
+// OFDM.py:490): larger * sqrt(fma(r, r, 1)) with r = smaller / larger, r = 0 when larger == 0 or smaller == inf;
+// an infinite part makes both parts infinite, a NaN part makes both NaN.  Every step is correctly rounded here as
+// there, so the value is bit-identical (tests/golden g5: 185 556 distances) -- which is what decides exact and
+// near ties of the hard demapper: two different squared distances can round to the same |.|, and argmin then
+// returns the first of them.
+GF3_DEV double np_cabs(double x, double y) {
+    double re = fabs(x), im = fabs(y);
+    const bool rinf = re == INFINITY, iinf = im == INFINITY;
+    if (rinf) im = INFINITY;
+    if (iinf) re = INFINITY;
+    const bool rnan = re != re, inan = im != im;
+    if (rnan) im = re;
+    if (inan) re = im;
+    const double larger = fmax(re, im), smaller = fmin(im, re);      // (both NaN when either is)
+    const bool nodiv = larger == 0.0 || smaller == INFINITY;
+    const double ratio = nodiv ? 0.0 : smaller / larger;
+    return sqrt(fma(ratio, ratio, 1.0)) * larger;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0),
 // which would make every FFT barrier wait for the next symbol's prefetch loads; here global
 // loads stay in flight across the barrier (their consumers get their own s_waitcnt).

@@ -123,3 +123,62 @@ def max_over_ranks(x: float, device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def spawn_ranks(cmd, n, port=None, env=None, relay=None, poll_s=0.2, grace_s=10.0):
+    """Start `cmd` (an argv list) n times as FRESH processes, one per rank, with the torchrun environment
+    (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT) and wait for all of them.
+
+    What `python bench.py --gpus N` does when it was not started under torchrun.  The caller must not have touched
+    the GPU: the children are plain subprocess.Popen children (never os.exec*), each initialises its own device.
+    Rank 0's stdout is relayed line by line through `relay` (default: print), the other ranks' stdout is dropped
+    (they print nothing by contract), stderr is inherited.  If a rank exits non-zero the others are given
+    `grace_s` seconds and then terminated by their exact PIDs.  Returns (rc, rank-0 stdout lines): rc is 0 only if
+    every rank returned 0, else the first non-zero code by rank order."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    if port is None:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    relay = relay or (lambda line: (sys.stdout.write(line + "\n"), sys.stdout.flush()))
+    procs = []
+    for r in range(n):
+        e = dict(os.environ if env is None else env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(list(cmd), env=e, text=True,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    lines = []
+    import threading
+
+    def pump():
+        for line in procs[0].stdout:
+            line = line.rstrip("\n")
+            lines.append(line)
+            relay(line)
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = time.monotonic()
+        if failed_at is not None and time.monotonic() - failed_at > grace_s:
+            for p in procs:                                   # exact PIDs of our own children only
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=5)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(poll_s)
+    t.join(timeout=5)
+    rcs = [p.wait() for p in procs]
+    rc = next((c for c in rcs if c != 0), 0)
+    return rc, lines
+

@@ -187,12 +187,15 @@ class Engine:
         self._check(self.lib.gf3_chirp_replica(self._h, out.ctypes.data_as(_lib.c_double_p)))
         return out
 
-    def rfft_batch(self, x, offsets):
+    def rfft_batch(self, x, offsets, out=None):
         """[n_sym, N/2+1] complex128 spectra of the N samples starting at each offset."""
         x = self._samples(x)
         offsets = torch.as_tensor(offsets, dtype=torch.int64).to(self.device).contiguous()
         n = offsets.numel()
-        out = self._new((n, self.cfg.N // 2 + 1), torch.complex128)
+        if out is None:
+            out = self._new((n, self.cfg.N // 2 + 1), torch.complex128)
+        elif out.dtype != torch.complex128 or out.numel() != n * (self.cfg.N // 2 + 1) or not out.is_contiguous():
+            raise ValueError("out must be a contiguous complex128 tensor of n_sym * (N/2+1) elements")
         self._check(self.lib.gf3_rfft_batch(self._h, _ptr(x), x.numel(), _ptr(offsets), n, _ptr(out), self._stream()))
         return out
 
@@ -301,9 +304,14 @@ class Engine:
         self._check(self.lib.gf3_demap_hard(self._h, _ptr(sym), n, _ptr(bits), _ptr(idx), self._stream()))
         return bits, idx
 
-    def soft_demap(self, sym, noise_var):
+    def soft_demap(self, sym, noise_var, out=None):
         sym = torch.as_tensor(sym, dtype=torch.complex128).to(self.device).contiguous()
-        llr = self._new(tuple(sym.shape) + (self.cfg.mu,), torch.float32)
+        if out is None:
+            llr = self._new(tuple(sym.shape) + (self.cfg.mu,), torch.float32)
+        elif out.dtype != torch.float32 or out.numel() != sym.numel() * self.cfg.mu or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 tensor of n * mu elements")
+        else:
+            llr = out
         self._check(self.lib.gf3_soft_demap(self._h, _ptr(sym), sym.numel(), float(noise_var), _ptr(llr), self._stream()))
         return llr
 

@@ -159,6 +159,31 @@ def matched_filter(r, p: RxParams):
     return np.fft.irfft(R * Cf, nfft)[:n]
 
 
+def matched_filter_chunked(r, p: RxParams, log2_fft=22, workers=None):
+    """The same full convolution for streams too long for one transform (BASELINE config 3 at full size:
+    321 M samples): overlap-save on the CPU, each block one zero-padded real FFT product of 2**log2_fft points
+    (scipy.fft, `workers` threads).  Agrees with matched_filter to rounding (tests/test_oracle_golden.py)."""
+    import scipy.fft as sfft
+    r = np.asarray(r, dtype=np.float64)
+    c = chirp_replica(p)
+    Lc, n = len(c), len(r)
+    nfft = 1 << log2_fft
+    B = nfft - Lc + 1                                    # valid outputs per block
+    assert B > 0
+    Cf = sfft.rfft(c[::-1], nfft)
+    out = np.empty(n + Lc - 1)
+    for m0 in range(0, n + Lc - 1, B):
+        lo = m0 - (Lc - 1)                               # first sample that reaches output m0
+        seg = np.zeros(nfft)
+        a, b = max(lo, 0), min(lo + nfft, n)
+        if b > a:
+            seg[a - lo: b - lo] = r[a:b]
+        y = sfft.irfft(sfft.rfft(seg, workers=workers) * Cf, nfft, workers=workers)
+        m1 = min(m0 + B, n + Lc - 1)
+        out[m0:m1] = y[Lc - 1: Lc - 1 + (m1 - m0)]       # linear convolution values (the first Lc-1 wrap around)
+    return out
+
+
 def matched_filter_direct(r, p: RxParams, m_idx):
     """Literal time-domain value of P at the listed full-convolution indices
     (slow; used to cross-check the FFT forms on a handful of lags)."""

@@ -113,3 +113,61 @@ def test_unpack_bits_layout_cpu():
     packed = torch.from_numpy(np.packbits(bits, axis=1))
     got = Engine.unpack_bits(Fake, packed).numpy()
     assert np.array_equal(got, bits.reshape(-1))
+
+
+STUB = r'''
+import json, os, sys
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+assert int(os.environ["MASTER_PORT"]) > 0
+mode = sys.argv[1]
+if mode == "fail" and rank == 1:
+    sys.exit(7)
+if mode == "hang-after-fail" and rank == 0:
+    import time; time.sleep(600)
+if mode == "hang-after-fail" and rank == 1:
+    sys.exit(5)
+print("noise from rank", rank, file=sys.stderr)
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "argv": sys.argv[1:]}))
+else:
+    print("rank", rank, "must not reach the parent's stdout")
+'''
+
+
+def test_spawn_ranks_env_rc_and_single_json_line(tmp_path):
+    """The launcher behind `python bench.py --gpus N` (no torchrun): fresh child processes with torchrun's
+    environment, rank 0's stdout relayed (exactly one JSON line), other ranks' stdout dropped, a failing rank's
+    code propagated, and stragglers of a failed run terminated instead of waited for."""
+    import json, time
+    from gf3_audio_modem_amd.dist import spawn_ranks
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    got = []
+    rc, lines = spawn_ranks([sys.executable, str(stub), "ok", "--gpus", "2"], 2, relay=got.append)
+    assert rc == 0 and lines == got and len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"n_gpus": 2, "argv": ["ok", "--gpus", "2"]}
+    rc, lines = spawn_ranks([sys.executable, str(stub), "fail"], 2, relay=got.append)
+    assert rc == 7
+    t0 = time.monotonic()
+    rc, lines = spawn_ranks([sys.executable, str(stub), "hang-after-fail"], 2, relay=got.append, grace_s=1.0)
+    assert rc != 0 and time.monotonic() - t0 < 60 and lines == []
+
+
+def test_bench_parent_launches_ranks_without_touching_the_gpu(tmp_path, monkeypatch):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset takes the launcher path before any device work: with the
+    rank command replaced by a stub the parent relays one JSON line and exits with the ranks' code."""
+    import json
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    env = dict(os.environ, GF3_BENCH_RANK_CMD=json.dumps([sys.executable, str(stub), "ok"]))
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and json.loads(out[0])["n_gpus"] == 2
+    env["GF3_BENCH_RANK_CMD"] = json.dumps([sys.executable, str(stub), "fail"])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7

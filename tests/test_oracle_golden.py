@@ -151,3 +151,15 @@ def test_schmidl_cox_matches_reference():
     assert orc.schmidl_cox(g["r"].astype(np.float64), p) == int(g["index"])
     with pytest.raises(IndexError):
         orc.schmidl_cox(g["r"][:1000].astype(np.float64), p)
+
+
+def test_chunked_matched_filter_equals_the_one_shot_form():
+    """oracle.matched_filter_chunked (overlap-save, used for the 321 M-sample config-3 stream) against
+    oracle.matched_filter on a fixture stream, for block sizes that do and do not divide the output."""
+    g = load("g1_n1024_qpsk")
+    p = params_of(g)
+    P = orc.matched_filter(g["r"], p)
+    for lf in (13, 14, 16):
+        Q = orc.matched_filter_chunked(g["r"], p, log2_fft=lf, workers=2)
+        assert Q.shape == P.shape and np.abs(P - Q).max() <= 1e-13 * np.abs(P).max()
+        assert np.array_equal(np.flatnonzero(orc.pick_peaks(Q, p.Lc, len(g["r"]), p.thresh)), g["peaks"])

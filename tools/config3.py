@@ -42,7 +42,7 @@ def make_stream(eng, channel, F, seed=3):
     return r, payload
 
 
-def measure(eng, cfg, r, payload, reps=3):
+def measure(eng, cfg, r, payload, reps=3, worst=3):
     """-> (result dict, starts int64 [F], packed bits uint8 [F, bytes_per_frame])"""
     F = payload.shape[0]
     torch.cuda.synchronize()
@@ -64,7 +64,7 @@ def measure(eng, cfg, r, payload, reps=3):
     # the measured channel delays the correlation peak by one sample
     exp = 64 + np.arange(F) * cfg.frame_len + cfg.chirp_length + 1
     res["sync_offsets_as_expected_plus1"] = bool(np.array_equal(starts.cpu().numpy(), exp))
-    res["worst_packets"] = np.argsort(per)[-3:].tolist()
+    res["worst_packets"] = np.argsort(per)[-worst:].tolist()
     return res, starts, out
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The reference's own default geometry (mode A2: N=4096, CP=224, P=20, D=180, data bins 200..1599, QPSK) at batch
+"""The reference's own default geometry (mode A2: N=4096, CP=224, P=20, D=180, data bins 100..1499, QPSK) at batch
 scale: F packets synthesised on the device, windowed chirp sync + fused demodulation, every bit checked.
 Reports samples/s (not the BASELINE metric's configuration; a data point for DESIGN.md)."""
 import argparse, json, os, sys
@@ -16,7 +16,7 @@ K = N // 2 - 1
 pts, bt = qpsk_table()
 known = np.unpackbits(np.load(os.path.join(ROOT, "gf3_audio_modem_amd", "data", "known_bits.npz"))["packed"])
 known = np.tile(known, -(-K * 2 // len(known)))
-bins = np.arange(200, 1600)                                         # OFDM.py mode "A2" band (lowest_bin 200, highest_bin 1600)
+bins = np.arange(100, 1500)                                         # mode "A2": lowest_bin 100, highest_bin 1500 exclusive (OFDM.py:32,47)
 cfg = RxConfig(N=N, CP=CP, P=P, D=D, data_bins=bins, const_points=pts, const_bits=bt, known_bits=known,
                in_dtype=torch.float32, max_window=320)
 eng = Engine(cfg)
