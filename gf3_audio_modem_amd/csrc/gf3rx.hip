@@ -24,6 +24,15 @@ struct SepTab {
     int maskI;                  // label bits owned by the I axis
 };
 
+// The same kind of table when, in addition, the levels of each axis are equally spaced (square Gray QAM, the reference
+// QPSK): the nearest level is then one rint() away.  Levels are numbered in ascending order here; pack holds the
+// label bits the i-th level contributes, one byte each (mu <= 8).  nI = 0: not such a table.
+struct UniGrid {
+    int nI, nQ;
+    double loI, invI, loQ, invQ;             // lowest level and 1 / spacing per axis
+    unsigned long long packI, packQ;
+};
+
 struct FftTables {
     const cplx* tw;    // [NC]      exp(-2 pi i m / NC)
     const cplx* twn;   // [NC/2+1]  exp(-2 pi i k / N)
@@ -54,7 +63,7 @@ struct DemodArgs {
     const cplx* sp_end;       // [F, P, K]
     cplx* eq_all;             // [F*D, K] equalised symbols on all carriers
     double qpsk_q;            // >0: table is the reference QPSK table (+-q +-qj): decide by signs away from ties
-    SepTab sep;
+    UniGrid ug;
     unsigned long long* stamps;   // diagnostic build only (-DGF3_STAMPS): [F][8] s_memtime per phase
 };
 
@@ -139,23 +148,6 @@ GF3_DEV uint32_t qpsk_sign_rule(cplx e) {
     return lab;
 }
 
-// Nearest level on one axis with the margin to the runner-up; first minimum wins like argmin.
-GF3_DEV int sep_axis(double x, const double* lv, int n, bool& clear) {
-    double d0 = (x - lv[0]) * (x - lv[0]), d1 = INFINITY;
-    int best = 0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i) {                   // <= 8 levels per axis (M <= 64); n is wave-uniform
-        if (i < n) {
-            const double d = (x - lv[i]) * (x - lv[i]);
-            const bool lt = d < d0;
-            d1 = lt ? d0 : fmin(d1, d);             // runner-up (fmin: a NaN d leaves it, as `d < d1` did)
-            best = lt ? i : best;
-            d0 = lt ? d : d0;
-        }
-    }
-    clear = (d1 - d0) > 1e-9 * (d1 + d0);       // false also for NaN / Inf inputs
-    return best;
-}
 // First-minimum scan over the whole table, deciding as `argmin(abs(sym - table))` does (OFDM.py:490-496).
 // Squared distances order the points exactly as the reference's distances do unless two of them agree to within
 // rounding; then (margin 1e-12 relative, four orders above the rounding of either form) the contenders are
@@ -190,17 +182,17 @@ GF3_DEV int scan_table(cplx e, const double* cre, const double* cim, int M) {
     }
     return best;
 }
-// hard decision -> label: per-axis when the table separates and neither axis is near a tie
-GF3_DEV uint32_t decide_label(cplx e, const SepTab& sp, const double* cre, const double* cim, const int* clab, int M) {
-    if (sp.nI > 0) {
-        bool ci, cq;
-        const int a = sep_axis(e.x, sp.lvI, sp.nI, ci);
-        const int b = sep_axis(e.y, sp.lvQ, sp.nQ, cq);
-        if (ci && cq) return (uint32_t)(sp.labI[a] | sp.labQ[b]);
-    }
-    return (uint32_t)clab[scan_table(e, cre, cim, M)];
+// Nearest of n equally spaced levels lo, lo + 1/inv, ...: index in units of the spacing by one rint().  `clear` is
+// false within 1e-9 of a spacing of a decision boundary (and for NaN / Inf), where the caller falls back to the
+// literal scan; everywhere else the per-axis choice IS the argmin over the grid, with a margin nine orders above the
+// rounding of either evaluation.
+GF3_DEV uint32_t uni_axis(double x, double lo, double inv, int n, unsigned long long pack, bool& clear) {
+    const double t = (x - lo) * inv;
+    const double r = fmin(fmax(rint(t), 0.0), (double)(n - 1));
+    const double d = fabs(t - r);
+    clear = (d < 1e300) && !(fabs(0.5 - d) < 1e-9);
+    return (uint32_t)(pack >> (8 * (int)r)) & 0xffu;
 }
-
 // MODE_FULL : per-symbol dumps (eq, eq_all, Hest) + literal table scan on the equalised symbol
 // MODE_SCAN : bits only, any constellation: normalise and scan literally
 // MODE_QPSK : bits only, reference QPSK table.  The channel magnitude model
@@ -211,10 +203,16 @@ enum { MODE_FULL = 0, MODE_SCAN = 1, MODE_QPSK = 2 };
 #define GF3_DEMOD_WPS 2
 #endif
 // lean modes at GF3_DEMOD_WPS waves/SIMD; 3 needs the single in-place FFT buffer to fit 3 workgroups of LDS
+// MODE_QPSK keeps the two ping-pong FFT buffers.  The table modes carry two more doubles of state per carrier (the
+// magnitude model a0 + da f_l), which do not fit the register file next to the transform at two workgroups per CU;
+// they live in LDS ([8][T] pairs, one conflict-free 16-byte read per carrier per symbol), and the room comes from the
+// single in-place FFT buffer (one more barrier per exchange).
 template <int NC, int MODE> struct DemodOcc {
-    static constexpr int WPS = (MODE != MODE_FULL && NC <= 2048) ? GF3_DEMOD_WPS : 2;
-    static constexpr bool PP = FftGeom<NC>::PINGPONG && WPS <= 2;
+    static constexpr int WPS = (MODE == MODE_QPSK && NC <= 2048) ? GF3_DEMOD_WPS : 2;
+    static constexpr bool MAG_LDS = (MODE != MODE_QPSK);
+    static constexpr bool PP = FftGeom<NC>::PINGPONG && WPS <= 2 && !MAG_LDS;
     static constexpr int LDS_ELEMS = PP ? FftGeom<NC>::LDS_ELEMS : FftGeom<NC>::LDS_ELEMS_INPLACE;
+    static constexpr int MAG_ELEMS = MAG_LDS ? NC : 0;             // double2 (a0, da) per slot per thread: 8 * NC/8
 };
 
 template <int NC, int DT, bool SPECTRA, int MODE>
@@ -225,7 +223,8 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     // LDS: [scratch 32 doubles | start-up rotation tables | FFT buffer | decision bytes | (fit-range overflow)]
     double* scratch = (double*)smem;
     cplx* rtab = (cplx*)(scratch + 32);                                   // [2][64 + NC/64 + 1]
-    cplx* lds = rtab + 2 * (64 + NC / 64 + 1);                            // FFT buffer, DemodOcc::LDS_ELEMS points
+    double2* mags = (double2*)(rtab + 2 * (64 + NC / 64 + 1));            // [8][T] (a0, da) of slot s of thread t (table modes)
+    cplx* lds = (cplx*)(mags + DemodOcc<NC, MODE>::MAG_ELEMS);            // FFT buffer, DemodOcc::LDS_ELEMS points
     uint8_t* labs = (uint8_t*)(lds + DemodOcc<NC, MODE>::LDS_ELEMS);      // [ring][C] decisions, one byte each
     const int tid = threadIdx.x;
     const int64_t f = blockIdx.x;
@@ -336,7 +335,6 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     cplx* hsl = lds;
     cplx* hel = hsl + L;                              // [L] same for He
     cplx u[8];
-    double a0[8], da[8];
     // The transforms of this kernel leave 2 X in the slots (rfft_regs<.., TWICE>): XS is that factor (1 when the
     // spectra come from memory).  It is divided out of the pilots here and carried by the magnitudes a0, da, so the
     // channel estimates are true-scale and X/Hest is unchanged -- bit for bit, powers of two being exact.
@@ -355,8 +353,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         if constexpr (MODE != MODE_QPSK) {
             const double e2 = He[s].x * He[s].x + He[s].y * He[s].y;
             const double ah = m2 * ia;                                // |Hs|
-            a0[s] = XS * ah;
-            da[s] = XS * (e2 * rsq_nr(e2) - ah);                      // XS (|He| - |Hs|)
+            mags[s * T + tid] = make_double2(XS * ah, XS * (e2 * rsq_nr(e2) - ah));   // XS |Hs|, XS (|He| - |Hs|)
         }
         u[s] = cmk(Hs[s].x * ia, Hs[s].y * ia);
     }
@@ -479,7 +476,8 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     }
     // data position of every slot, resolved once: a lookup inside the symbol loop would put a vmcnt(0) wait
     // behind the packed-word stores and the next symbol's prefetch
-    // (QPSK mode; the other modes have no registers to spare for it)
+    // (QPSK mode; the table modes have no registers to spare for it and recompute the position per symbol --
+    //  plain arithmetic for a contiguous band)
     int psl[8];
     if constexpr (MODE == MODE_QPSK) {
 #pragma unroll
@@ -512,18 +510,19 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 #pragma unroll
             for (int s = 0; s < 8; ++s) if (psl[s] >= 0) lab_l[psl[s]] = (uint8_t)lab[s];
         } else {
+            // Fast path, straight-line over the eight carriers: equalise, then the nearest grid point per axis
+            // (decide_fast).  A decision within 1e-9 of a spacing of a boundary, a NaN / Inf symbol or a table that
+            // is not a uniform grid is only MARKED here; the marked carriers are re-decided below by the literal scan.
+            uint32_t unclear = 0;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int n = bin_of(s) - 1;
-            const cplx g = u[s];                                           // unit phasor of Hest for this symbol
-            const cplx ep = cmul_conj(v[s], g);                            // X / g  = e * mag
-            u[s] = cmul(g, gstep[s]);                                      // ... and for the next one
-            const int ps = (MODE == MODE_QPSK) ? psl[s] : pos_of(s);
-            if constexpr (MODE == MODE_QPSK) {
-                if (ps >= 0) lab_l[ps] = (uint8_t)qpsk_sign_rule(ep);
-                if (s & 1) __builtin_amdgcn_sched_barrier(0);   // two carriers at a time: bounds the loads in flight
-            } else {
-                const double mag = fma(da[s], fl, a0[s]);
+            for (int s = 0; s < 8; ++s) {
+                const int n = bin_of(s) - 1;
+                const cplx g = u[s];                                       // unit phasor of Hest for this symbol
+                const cplx ep = cmul_conj(v[s], g);                        // X / g  = e * mag
+                u[s] = cmul(g, gstep[s]);                                  // ... and for the next one
+                const int ps = pos_of(s);
+                const double2 md = mags[s * T + tid];
+                const double mag = fma(md.y, fl, md.x);
                 const cplx e = cscale(ep, rcp_nr(mag));
                 if constexpr (FULL) {
                     if (live_of(s)) {
@@ -533,10 +532,33 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
                     if (ps >= 0 && a.eq) a.eq[((int64_t)f * D + l) * C + ps] = e;
                 }
                 if (ps >= 0) {
-                    lab_l[ps] = (uint8_t)decide_label(e, a.sep, a.cre, a.cim, a.clab, a.M);
+                    bool ci, cq;
+                    const uint32_t li = uni_axis(e.x, a.ug.loI, a.ug.invI, a.ug.nI, a.ug.packI, ci);
+                    const uint32_t lq = uni_axis(e.y, a.ug.loQ, a.ug.invQ, a.ug.nQ, a.ug.packQ, cq);
+                    lab_l[ps] = (uint8_t)(li | lq);
+                    if (!(ci && cq && a.ug.nI > 0)) unclear |= 1u << s;
                 }
             }
-        }
+            // Rare path, one marked carrier at a time (no unrolling: nothing of the transform is live here, and the
+            // slot's operands are picked out of the register arrays by selects).  The symbol is rebuilt from the
+            // spectrum still in v[]: the phasor has already been advanced, g = u * conj(gstep) undoes that.
+            for (uint32_t m = unclear; m; m &= m - 1) {
+                const int s = __ffs((int)m) - 1;
+                cplx vs = v[0], us = u[0], gs = gstep[0];
+                const double2 md = mags[s * T + tid];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    const bool hit = (s == k);
+                    vs = cmk(hit ? v[k].x : vs.x, hit ? v[k].y : vs.y);
+                    us = cmk(hit ? u[k].x : us.x, hit ? u[k].y : us.y);
+                    gs = cmk(hit ? gstep[k].x : gs.x, hit ? gstep[k].y : gs.y);
+                }
+                const int bn = Spec<NC>::bin(tid, s);                      // (a marked slot is live and a data carrier)
+                const int ps = a.contig_lo > 0 ? bn - a.contig_lo : a.pos[bn - 1];
+                const cplx g = cmul_conj(us, gs);
+                const cplx e = cscale(cmul_conj(vs, g), rcp_nr(fma(md.y, fl, md.x)));
+                lab_l[ps] = (uint8_t)a.clab[scan_table(e, a.cre, a.cim, a.M)];
+            }
         }
     }
     GF3_STAMP(4);
@@ -1219,6 +1241,7 @@ struct gf3_ctx {
     double* d_chirp = nullptr;
     double* d_known_time = nullptr;     // one pilot symbol in the time domain (transmit side)
     SepTab sep{};
+    UniGrid ug{};
     unsigned long long* stamps = nullptr;
     int contig_lo = 0;
     int device = 0;                     // HIP device the context (tables, plans) lives on
@@ -1453,6 +1476,31 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
             }
         }
     }
+    // equally spaced levels on both axes?  (sorted ascending; spacing equal to 1e-12 relative)
+    {
+        const SepTab& sp = c->sep;
+        UniGrid& ug = c->ug;
+        ug = UniGrid{};
+        auto axis = [](const double* lv, const int* lab, int n, double& lo, double& inv, unsigned long long& pack) -> bool {
+            if (n < 2 || n > 8) return false;
+            int order[8];
+            for (int i = 0; i < n; ++i) order[i] = i;
+            for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) if (lv[order[j]] < lv[order[i]]) { int t = order[i]; order[i] = order[j]; order[j] = t; }
+            const double step = (lv[order[n - 1]] - lv[order[0]]) / (n - 1);
+            if (!(step > 0.0)) return false;
+            pack = 0;
+            for (int i = 0; i < n; ++i) {
+                if (fabs(lv[order[i]] - (lv[order[0]] + i * step)) > 1e-12 * step) return false;
+                if (lab[order[i]] & ~0xff) return false;
+                pack |= (unsigned long long)(lab[order[i]] & 0xff) << (8 * i);
+            }
+            lo = lv[order[0]]; inv = 1.0 / step;
+            return true;
+        };
+        if (sp.nI > 0 && axis(sp.lvI, sp.labI, sp.nI, ug.loI, ug.invI, ug.packI) && axis(sp.lvQ, sp.labQ, sp.nQ, ug.loQ, ug.invQ, ug.packQ)) {
+            ug.nI = sp.nI; ug.nQ = sp.nQ;
+        } else ug.nI = ug.nQ = 0;
+    }
     // the reference's QPSK table (OFDM.py:72-77): (+,+)00 (+,-)10 (-,-)11 (-,+)01 with |re|=|im|
     if (cfg->M == 4 && cfg->mu == 2) {
         const double q = cfg->const_re[0];
@@ -1571,9 +1619,10 @@ static int demod_ring(const gf3_ctx* c) {
     while (r < need) r <<= 1;
     return r;
 }
+// lean = MODE_QPSK (ping-pong FFT buffers); the table modes use the in-place buffer plus NC (a0, da) pairs
 static size_t demod_lds_bytes(const gf3_ctx* c, bool lean = false) {
-    const bool inplace = lean && GF3_DEMOD_WPS > 2 && c->NC <= 2048;
-    const size_t fft = inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC);
+    const bool inplace = !lean || (GF3_DEMOD_WPS > 2 && c->NC <= 2048);
+    const size_t fft = (inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC)) + (lean ? 0 : (size_t)c->NC * sizeof(double2));
     const size_t tail = fft + (size_t)((demod_ring(c) * c->cfg.C + 15) & ~15);  // FFT buffer + decision bytes ...
     const size_t fit = (size_t)2 * (c->fit_hi - c->fit_lo) * sizeof(cplx);      // ... overlaid by Hs, He of the fit range
     return 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) + (fit > tail ? fit : tail);
@@ -1591,14 +1640,14 @@ extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, cons
                 c->d_known, c->d_pos, c->contig_lo, demod_ring(c), c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, (cplx*)d_eq, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, d_status,
-                nullptr, nullptr, nullptr, nullptr, c->qpsk_q, c->sep, c->stamps};
+                nullptr, nullptr, nullptr, nullptr, c->qpsk_q, c->ug, c->stamps};
     hipError_t e = hipSuccess;
     if (d_eq || d_Hest) {
         DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_FULL>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
     } else if (c->qpsk_q > 0.0) {
         DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_QPSK>), F, NCC / 8, demod_lds_bytes(c, true), (hipStream_t)stream, a));
     } else {
-        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_SCAN>), F, NCC / 8, demod_lds_bytes(c, true), (hipStream_t)stream, a));
+        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_SCAN>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
     }
     HIPCHK(c, e);
     return GF3_OK;
@@ -1616,7 +1665,7 @@ extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start,
                 c->d_known, c->d_pos, c->contig_lo, demod_ring(c), c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, nullptr, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, nullptr,
-                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_q, c->sep, nullptr};
+                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_q, c->ug, nullptr};
     hipError_t e = hipSuccess;
     switch (c->NC) {
 #ifndef GF3_DEV_BUILD
