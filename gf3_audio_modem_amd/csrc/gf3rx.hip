@@ -10,6 +10,7 @@
 
 #include "gf3rx.h"
 #include "gf3rx_device.h"
+#include "gf3rx_screen.h"
 
 // ============================================================================
 // kernel argument blocks
@@ -1245,6 +1246,11 @@ struct gf3_ctx {
     unsigned long long* stamps = nullptr;
     int contig_lo = 0;
     int device = 0;                     // HIP device the context (tables, plans) lives on
+    // single-precision screening plan of the stream-mode sync (gf3rx_screen.h); ok = false: always the fp64 path
+    struct { bool ok = false; int Q = 0, H = 0; cf *d_tw = nullptr, *d_twn = nullptr; float4* d_Hs = nullptr;
+             float *d_H0N = nullptr, *d_Hinf = nullptr; } scr;
+    int stream_mode = 0;                // 0: screen first, fp64 when asked for P or when the screen is not selective; 1: fp64 only
+    int64_t last_info[4] = {0, 0, 0, 0};   // last gf3_sync_stream: path taken (0 screened, 1 fp64 after fallback, 2 fp64), cells A, cells B, candidates
     std::vector<double> chirp;
     std::vector<cplx> known_pts;
     mutable char err[512];
@@ -1383,6 +1389,67 @@ static int build_plan(gf3_ctx* c, CorrPlan* pl, int NCp, FftTables t, int Lp_max
 }
 
 static int build_known_time(gf3_ctx* c);
+
+// Screening plan (gf3rx_screen.h): fp32 spectra of the chirp partitions for 8192-sample windows, in the slot order
+// the kernel reads them, with max |H_q| per partition for the error bound.  The spectra are computed here on the
+// host in fp64 (iterative radix-2, a few hundred kflop) and rounded once.
+static void host_fft(std::vector<double>& re, std::vector<double>& im) {           // in place, length a power of two
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const long double ang = -6.283185307179586476925286766559005768L * (long double)k / (long double)len;
+                const double wr = (double)cosl(ang), wi = (double)sinl(ang);
+                const size_t a = i + k, b = i + k + len / 2;
+                const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] += xr; im[a] += xi;
+            }
+    }
+}
+static int build_screen_plan(gf3_ctx* c) {
+    constexpr int NC = GF3_SCR_NC, N = 2 * GF3_SCR_NC, T = GF3_SCR_T;
+    auto& sp = c->scr;
+    sp.ok = false;
+    const int Q = (c->Lc + NC - 1) / NC;
+    int H = (c->Lc + Q - 1) / Q;
+    H += H & 1;                                          // even: the kernel stores lag pairs
+    if (Q > 16 || H > NC || c->Lc < 16) return GF3_OK;   // (outside the plan's range: fp64 path only)
+    sp.Q = Q; sp.H = H;
+    std::vector<float> Hs((size_t)Q * 8 * T * 4), H0N((size_t)Q * 2), Hinf(Q);
+    for (int q = 0; q < Q; ++q) {
+        std::vector<double> re(N, 0.0), im(N, 0.0);
+        for (int k = 0; k < H && q * H + k < c->Lc; ++k) re[k] = c->chirp[(size_t)q * H + k];
+        host_fft(re, im);
+        double mx = 0.0;
+        for (int k = 0; k <= NC; ++k) mx = fmax(mx, hypot(re[k], im[k]));
+        Hinf[q] = (float)(mx * (1.0 + 1e-6));
+        H0N[2 * q] = (float)re[0]; H0N[2 * q + 1] = (float)re[NC];
+        for (int r = 0; r < 8; ++r)
+            for (int t = 0; t < T; ++t) {
+                const int k = (t == 0 && r == 0) ? NC / 2 : t + 256 * r;
+                float* o = &Hs[(((size_t)q * 8 + r) * T + t) * 4];
+                o[0] = (float)re[k]; o[1] = (float)im[k]; o[2] = (float)re[NC - k]; o[3] = (float)im[NC - k];
+            }
+    }
+    std::vector<float> tw(2 * NC), twn(2 * (NC / 2 + 1));
+    const long double PI2 = 6.283185307179586476925286766559005768L;
+    for (int m = 0; m < NC; ++m) { const long double a = -PI2 * m / NC; tw[2 * m] = (float)cosl(a); tw[2 * m + 1] = (float)sinl(a); }
+    for (int k = 0; k <= NC / 2; ++k) { const long double a = -PI2 * k / N; twn[2 * k] = (float)cosl(a); twn[2 * k + 1] = (float)sinl(a); }
+    HIPCHK(c, upload((float**)&sp.d_tw, tw.data(), tw.size()));
+    HIPCHK(c, upload((float**)&sp.d_twn, twn.data(), twn.size()));
+    HIPCHK(c, upload((float**)&sp.d_Hs, Hs.data(), Hs.size()));
+    HIPCHK(c, upload(&sp.d_H0N, H0N.data(), H0N.size()));
+    HIPCHK(c, upload(&sp.d_Hinf, Hinf.data(), Hinf.size()));
+    sp.ok = true;
+    return GF3_OK;
+}
 
 extern "C" const char* gf3_version(void) { return GF3RX_VERSION; }
 
@@ -1575,6 +1642,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     int rc = build_plan(c, &c->frames_plan, NCf, tf, 2 * NCf - wmax + 1);
     if (rc == GF3_OK) rc = build_plan(c, &c->stream_plan, NCs, ts, NCs);
     if (rc == GF3_OK) rc = build_known_time(c);
+    if (rc == GF3_OK) rc = build_screen_plan(c);
     if (rc != GF3_OK) { memcpy(g_err, c->err, 512); gf3_ctx_destroy(c); return rc; }
     *out = c;
     return GF3_OK;
@@ -1584,7 +1652,8 @@ extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
     if (!c) return;
     DeviceGuard dg(c);
     void* ptrs[] = {c->d_tw_x[0], c->d_twn_x[0], c->d_tw_x[1], c->d_twn_x[1], c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
-                    c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_known_time};
+                    c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_known_time,
+                    c->scr.d_tw, c->scr.d_twn, c->scr.d_Hs, c->scr.d_H0N, c->scr.d_Hinf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete c;
 }
@@ -1619,13 +1688,16 @@ static int demod_ring(const gf3_ctx* c) {
     while (r < need) r <<= 1;
     return r;
 }
-// lean = MODE_QPSK (ping-pong FFT buffers); the table modes use the in-place buffer plus NC (a0, da) pairs
+// lean = MODE_QPSK (ping-pong FFT buffers); the table modes use the in-place buffer and, ahead of it, NC (a0, da) pairs.
+// Layout: [scratch 32 doubles | rotation tables | (a0, da) pairs | FFT buffer | decision bytes], the last two overlaid
+// by Hs, He of the fit range during the channel-estimate stage (which may need more than they hold).
 static size_t demod_lds_bytes(const gf3_ctx* c, bool lean = false) {
     const bool inplace = !lean || (GF3_DEMOD_WPS > 2 && c->NC <= 2048);
-    const size_t fft = (inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC)) + (lean ? 0 : (size_t)c->NC * sizeof(double2));
-    const size_t tail = fft + (size_t)((demod_ring(c) * c->cfg.C + 15) & ~15);  // FFT buffer + decision bytes ...
-    const size_t fit = (size_t)2 * (c->fit_hi - c->fit_lo) * sizeof(cplx);      // ... overlaid by Hs, He of the fit range
-    return 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) + (fit > tail ? fit : tail);
+    const size_t fft = inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC);
+    const size_t mags = lean ? 0 : (size_t)c->NC * sizeof(double2);
+    const size_t tail = fft + (size_t)((demod_ring(c) * c->cfg.C + 15) & ~15);
+    const size_t fit = (size_t)2 * (c->fit_hi - c->fit_lo) * sizeof(cplx);
+    return 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) + mags + (fit > tail ? fit : tail);
 }
 
 extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,
@@ -1854,7 +1926,10 @@ extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64
 }
 
 // workspace layout for gf3_sync_stream
-struct StreamWs { int64_t plen, nz, nb_max, nb_c, nblk, nwin; size_t o_P, o_part, o_cnt, o_off, o_cand, o_misc, o_spec, total; };
+struct StreamWs { int64_t plen, nz, nb_max, nb_c, nblk, nwin; size_t o_P, o_part, o_cnt, o_off, o_cand, o_misc, o_spec, total;
+                  // screened path (gf3rx_screen.h); P32 overlays o_P, the per-workgroup counts / offsets overlay o_cnt / o_off
+                  int64_t s_nblk, s_ncell, s_nwg, s_capA, s_capB;
+                  size_t o_sblk, o_smisc, o_cellA, o_cmaxA, o_cellB, o_maskB, o_cntB, o_offB; };
 static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
     StreamWs w;
     w.plen = n + c->Lc - 1; w.nz = w.plen - 2;
@@ -1874,12 +1949,125 @@ static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
     w.nblk = (w.plen + c->stream_plan.Lp - 1) / c->stream_plan.Lp;
     w.nwin = w.nblk + c->stream_plan.Q - 1;
     w.o_spec = take((size_t)w.nwin * (c->stream_plan.NC + 1) * sizeof(cplx));
+    w.s_nblk = w.s_ncell = w.s_nwg = w.s_capA = w.s_capB = 0;
+    if (c->scr.ok) {
+        w.s_nblk = (w.plen + c->scr.H - 1) / c->scr.H;
+        w.s_ncell = (w.nz + GF3_SCR_CELL - 1) / GF3_SCR_CELL;
+        if (w.s_ncell < 1) w.s_ncell = 1;
+        w.s_nwg = (w.s_ncell + SCR_LIST_THREADS - 1) / SCR_LIST_THREADS;
+        w.s_capA = 4096;
+        w.s_capB = w.s_ncell / 16 > 4096 ? w.s_ncell / 16 : 4096;
+        w.o_sblk = take((size_t)w.s_nblk * 8);                 // blk_max | blk_err (float each)
+        w.o_smisc = take(sizeof(ScrMisc));
+        w.o_cellA = take((size_t)w.s_capA * 8);
+        w.o_cmaxA = take((size_t)w.s_capA * 8);
+        w.o_cellB = take((size_t)w.s_capB * 8);
+        w.o_maskB = take((size_t)w.s_capB * 4);
+        w.o_cntB = take((size_t)w.s_capB * 8);
+        w.o_offB = take((size_t)w.s_capB * 8);
+        if ((size_t)w.s_nwg > (size_t)w.nb_c) {                // (cannot happen: 3584 lags per list workgroup vs 2048 per candidate block)
+            w.s_nblk = 0;
+        }
+    }
     w.total = o;
     return w;
 }
 extern "C" int64_t gf3_sync_stream_workspace_bytes(const gf3_ctx* c, int64_t n) {
     if (!c || n < 1) return 0;
     return (int64_t)stream_ws(c, n).total;
+}
+
+// Screened path of gf3_sync_stream (gf3rx_screen.h).  Enqueues everything on `st`; the caller reads back
+// {peaks, suppression status} at np and the ScrMisc block.  d_dbg (tests): fp64 values of the candidate cells.
+static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const StreamWs& w, char* base, int64_t* d_peaks,
+                                int64_t cap, double* d_dbg, hipStream_t st) {
+    const auto& sp = c->scr;
+    float* P32 = (float*)(base + w.o_P);
+    float* blk_max = (float*)(base + w.o_sblk);
+    float* blk_err = blk_max + w.s_nblk;
+    ScrMisc* misc = (ScrMisc*)(base + w.o_smisc);
+    int64_t* cnt = (int64_t*)(base + w.o_cnt);
+    int64_t* offs = (int64_t*)(base + w.o_off);
+    int64_t* total = (int64_t*)(base + w.o_misc + 8);
+    int64_t* np = (int64_t*)(base + w.o_misc + 16);
+    int64_t* cand = (int64_t*)(base + w.o_cand);
+    int64_t* cellA = (int64_t*)(base + w.o_cellA);
+    double* cmaxA = (double*)(base + w.o_cmaxA);
+    int64_t* cellB = (int64_t*)(base + w.o_cellB);
+    unsigned* maskB = (unsigned*)(base + w.o_maskB);
+    int64_t* cntB = (int64_t*)(base + w.o_cntB);
+    int64_t* offB = (int64_t*)(base + w.o_offB);
+    const int dt = c->cfg.in_dtype;
+    {
+        ScreenArgs a{d_r, n, dt, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, w.s_nblk, w.plen,
+                     P32, blk_max, blk_err};
+        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 4 * GF3_SCR_B) * sizeof(float);
+        const int64_t grid = (w.s_nblk + GF3_SCR_B - 1) / GF3_SCR_B;
+        hipError_t e = hipSuccess;
+        DISPATCH_DT(dt, e = launch((scr_ols_kernel<DTC>), grid, GF3_SCR_T, lds, st, a));
+        HIPCHK(c, e);
+    }
+    hipLaunchKernelGGL(scr_mlo_kernel, dim3(1), dim3(1024), 0, st, (const float*)blk_max, (const float*)blk_err, w.s_nblk, misc);
+    auto list_cells = [&](int which, int64_t* cells, int64_t capc) {
+        hipLaunchKernelGGL(scr_cells_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
+                           (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, which, cnt, (const int64_t*)nullptr,
+                           (int64_t*)nullptr, (int64_t)0);
+        hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.s_nwg, offs, total);
+        hipLaunchKernelGGL(scr_total_kernel, dim3(1), dim3(1), 0, st, (const int64_t*)total, capc, misc, which);
+        hipLaunchKernelGGL(scr_cells_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
+                           (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, which, cnt, (const int64_t*)offs,
+                           cells, capc);
+    };
+    auto refine = [&](int which, const int64_t* cells, int64_t capc) -> hipError_t {
+        RefineArgs a{d_r, n, dt, c->d_chirp, c->Lc, cells, misc, which, w.plen, w.nz, c->cfg.thresh, cmaxA, maskB, cntB,
+                     which == 1 ? d_dbg : nullptr};
+        hipError_t e = hipSuccess;
+        // fixed grid (the list length lives on the device): workgroups stride over the listed cells
+        const unsigned grid = (unsigned)(capc < 2048 ? capc : 2048);
+        DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine_kernel<DTC>), dim3(grid), dim3(SCR_REF_THREADS), 0, st, a); e = hipGetLastError());
+        return e;
+    };
+    list_cells(0, cellA, w.s_capA);
+    HIPCHK(c, refine(0, cellA, w.s_capA));
+    hipLaunchKernelGGL(scr_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)cmaxA, misc, c->cfg.thresh);
+    list_cells(1, cellB, w.s_capB);
+    HIPCHK(c, hipMemsetAsync(cntB, 0, (size_t)w.s_capB * 8, st));      // cells beyond the listed count contribute nothing
+    HIPCHK(c, refine(1, cellB, w.s_capB));
+    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cntB, w.s_capB, offB, total);
+    hipLaunchKernelGGL(scr_expand_kernel, dim3((unsigned)((w.s_capB + 255) / 256)), dim3(256), 0, st, (const int64_t*)cellB, (const unsigned*)maskB,
+                       (const int64_t*)offB, (const ScrMisc*)misc, cand, w.nz + 2);
+    hipLaunchKernelGGL(pk_nms, dim3(1), dim3(NMS_THREADS), 0, st, (const int64_t*)cand, (const int64_t*)total,
+                       (int64_t)c->Lc, w.nz, d_peaks, cap, np);
+    HIPCHK(c, hipGetLastError());
+    return GF3_OK;
+}
+
+extern "C" int gf3_sync_stream_mode(gf3_ctx* c, int32_t mode) {
+    if (!c || mode < 0 || mode > 1) return fail(c, GF3_EINVAL, "gf3_sync_stream_mode: mode must be 0 (screened) or 1 (fp64 only)");
+    c->stream_mode = mode;
+    return GF3_OK;
+}
+extern "C" int gf3_sync_stream_info(const gf3_ctx* c, int64_t* h_out4) {
+    if (!c || !h_out4) return fail(c, GF3_EINVAL, "null argument");
+    memcpy(h_out4, c->last_info, sizeof(c->last_info));
+    return GF3_OK;
+}
+// tests: the screening pass alone.  d_p32 [n + Lc - 1] float, d_blk [2 * nblk] float (block maxima, then block error
+// bounds), *h_hop = lags per block.
+extern "C" int gf3_debug_stream_screen(gf3_ctx* c, const void* d_r, int64_t n, float* d_p32, float* d_blk, int32_t* h_hop, void* stream) {
+    DeviceGuard dg(c);
+    if (!c || !d_r || !d_p32 || !d_blk || !h_hop || n < 3) return fail(c, GF3_EINVAL, "gf3_debug_stream_screen: bad argument");
+    if (!c->scr.ok) return fail(c, GF3_EINVAL, "gf3_debug_stream_screen: no screening plan for this geometry");
+    const auto& sp = c->scr;
+    const int64_t plen = n + c->Lc - 1, nblk = (plen + sp.H - 1) / sp.H;
+    *h_hop = sp.H;
+    ScreenArgs a{d_r, n, c->cfg.in_dtype, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, nblk, plen,
+                 d_p32, d_blk, d_blk + nblk};
+    const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 4 * GF3_SCR_B) * sizeof(float);
+    hipError_t e = hipSuccess;
+    DISPATCH_DT(a.dt, e = launch((scr_ols_kernel<DTC>), (nblk + GF3_SCR_B - 1) / GF3_SCR_B, GF3_SCR_T, lds, (hipStream_t)stream, a));
+    HIPCHK(c, e);
+    return GF3_OK;
 }
 
 extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* d_peaks, int64_t cap,
@@ -1899,6 +2087,26 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     int64_t* total = (int64_t*)(base + w.o_misc + 8);
     int64_t* np = (int64_t*)(base + w.o_misc + 16);        // [count, status]
     const CorrPlan& pl = c->stream_plan;
+    c->last_info[0] = 2; c->last_info[1] = c->last_info[2] = c->last_info[3] = 0;
+    if (!d_corr && c->stream_mode == 0 && c->scr.ok && w.s_nblk > 0) {
+        int rc = sync_stream_screened(c, d_r, n, w, base, d_peaks, cap, nullptr, st);
+        if (rc != GF3_OK) return rc;
+        int64_t h[2] = {0, 0};
+        ScrMisc hm;
+        HIPCHK(c, hipMemcpyAsync(h, np, 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(&hm, base + w.o_smisc, sizeof(ScrMisc), hipMemcpyDeviceToHost, st));
+        int64_t ncand = 0;
+        HIPCHK(c, hipMemcpyAsync(&ncand, total, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->last_info[1] = hm.ncellA; c->last_info[2] = hm.ncellB; c->last_info[3] = ncand;
+        if (!(hm.status & 1)) {
+            c->last_info[0] = 0;
+            *n_peaks = h[0];
+            if (h[1] == 2) return fail(c, GF3_ERANGE, "gf3_sync_stream: %lld peaks exceed capacity %lld", (long long)h[0], (long long)cap);
+            return GF3_OK;
+        }
+        c->last_info[0] = 1;                              // the screen was not selective: all-fp64 path below
+    }
     {
         OlsArgs a{};
         a.t = pl.t; a.in = d_r; a.n_in = n; a.dt = c->cfg.in_dtype;

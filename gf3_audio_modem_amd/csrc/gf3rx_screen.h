@@ -1,0 +1,508 @@
+// Stream-mode chirp sync, fast path: single-precision SCREENING of the matched filter + double-precision decisions.
+//
+// receiver.chirp_method (OFDM.py:356-372) needs, of the whole correlation P = convolve(r, chirp[::-1]):
+//   (1) its global maximum M, (2) the lags i with P[i+1]/M > thresh that are local extrema, (3) the suppression walk.
+// Only a handful of lags around every chirp ever pass (2).  So P is first evaluated in fp32 for EVERY lag (uniformly
+// partitioned overlap-save, forward transforms fused into the accumulation: no spectra in HBM), together with a bound
+// E_b on |P32 - P| for each output block; then
+//   * every lag whose upper bound P32 + E_b reaches the best lower bound  max(P32 - E_b)  could be the maximum:
+//     those lags are re-evaluated as fp64 dot products with the fp64 replica, and M is the largest of them;
+//   * every lag whose upper bound exceeds  thresh M (1 - 1e-6)  could pass (2): those lags and their two
+//     neighbours are re-evaluated in fp64 and the reference's rule is applied literally to the fp64 values.
+// No decision is ever taken on an fp32 value: fp32 only proves, with a margin, which lags need NOT be looked at.
+// If the screen is not selective (constant streams, pathological thresholds: more cells than the work list holds)
+// the caller falls back to the all-fp64 path (spec_kernel + ols_kernel), which is also what serves `d_corr`.
+//
+// The error bound.  Block b = sum over partitions q of the circular correlation of window b+q with partition q,
+// each evaluated as irfft(rfft(x) conj(H_q)) in fp32.  For one term, with u = 2^-24:
+//   |y32 - y|_inf <= |y32 - y|_2 <= g |x|_2 max_k|H_q[k]|,   g = (c_f + c_i) log2(N) u + c_m u
+// (forward and inverse transform errors are relative in the 2-norm and the inverse transform is a contraction by
+// 1/sqrt(N) after the forward one expanded by sqrt(N); products and the rounding of H_q and of fp64 samples to fp32
+// are c_m u).  A 16-point butterfly pass with three-deep twiddle products is good for <= 8 u per pass, three passes
+// plus the packed-real split per transform: g <~ 60 u.  The kernel uses GF3_SCR_GAMMA = 256 u; tests/ measure the
+// realised ratio on random, DC-biased and adversarial streams (it stays below 2 u).
+#pragma once
+#include "gf3rx_device.h"
+
+typedef float2 cf;
+#define GF3_SCR_NC 4096              /* complex points of the screening transform (8192 real samples per window) */
+#define GF3_SCR_T 256                /* threads per workgroup: 16 points each */
+#define GF3_SCR_B 4                  /* adjacent output blocks per workgroup (share their windows' transforms) */
+#define GF3_SCR_CELL 14              /* centre lags per refinement cell (16 fp64 values with the two neighbours) */
+#define GF3_SCR_GAMMA (256.0f * 5.9604645e-8f)
+
+GF3_DEV cf cfmk(float a, float b) { return make_float2(a, b); }
+GF3_DEV cf cfadd(cf a, cf b) { return cfmk(a.x + b.x, a.y + b.y); }
+GF3_DEV cf cfsub(cf a, cf b) { return cfmk(a.x - b.x, a.y - b.y); }
+GF3_DEV cf cfmul(cf a, cf b) { return cfmk(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x)); }
+GF3_DEV cf cfconj(cf a) { return cfmk(a.x, -a.y); }
+GF3_DEV cf cf_negi(cf a) { return cfmk(a.y, -a.x); }
+GF3_DEV cf cf_posi(cf a) { return cfmk(-a.y, a.x); }
+GF3_DEV cf cf_fma_conj(cf a, cf h, cf c) {            // c + a conj(h)
+    return cfmk(fmaf(a.x, h.x, fmaf(a.y, h.y, c.x)), fmaf(a.y, h.x, fmaf(-a.x, h.y, c.y)));
+}
+
+// 4-point DFT in place: (a, b, c, d) = x0..x3  ->  X0..X3
+GF3_DEV void scr_dft4(cf& a, cf& b, cf& c, cf& d) {
+    const cf s0 = cfadd(a, c), s1 = cfsub(a, c), s2 = cfadd(b, d), s3 = cf_negi(cfsub(b, d));
+    a = cfadd(s0, s2); c = cfsub(s0, s2); b = cfadd(s1, s3); d = cfsub(s1, s3);
+}
+// 16-point DFT in place as 4 x 4; output X[m] is left in v[scr_perm(m)]
+GF3_DEV constexpr int scr_perm(int m) { return (m >> 2) + 4 * (m & 3); }
+GF3_DEV void scr_dft16(cf (&v)[16]) {
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) scr_dft4(v[a], v[a + 4], v[a + 8], v[a + 12]);     // v[a + 4b] = T_a[b]
+    // T_a[b] *= W16^(a b)
+    v[1 + 4] = cfmul(v[1 + 4], cfmk(c1, -s1));  v[1 + 8] = cfmul(v[1 + 8], cfmk(h, -h));    v[1 + 12] = cfmul(v[1 + 12], cfmk(s1, -c1));
+    v[2 + 4] = cfmul(v[2 + 4], cfmk(h, -h));    v[2 + 8] = cf_negi(v[2 + 8]);               v[2 + 12] = cfmul(v[2 + 12], cfmk(-h, -h));
+    v[3 + 4] = cfmul(v[3 + 4], cfmk(s1, -c1));  v[3 + 8] = cfmul(v[3 + 8], cfmk(-h, -h));   v[3 + 12] = cfmul(v[3 + 12], cfmk(-c1, s1));
+#pragma unroll
+    for (int b = 0; b < 4; ++b) scr_dft4(v[4 * b], v[4 * b + 1], v[4 * b + 2], v[4 * b + 3]);   // v[c + 4b] = X[b + 4c]
+}
+// v[r] *= w^r, r = 1..15, products at most four deep
+GF3_DEV void scr_twiddle16(cf (&v)[16], cf w) {
+    const cf w2 = cfmul(w, w), w3 = cfmul(w2, w), w4 = cfmul(w2, w2);
+    v[1] = cfmul(v[1], w); v[2] = cfmul(v[2], w2); v[3] = cfmul(v[3], w3); v[4] = cfmul(v[4], w4);
+    const cf w5 = cfmul(w4, w), w6 = cfmul(w4, w2), w7 = cfmul(w4, w3), w8 = cfmul(w4, w4);
+    v[5] = cfmul(v[5], w5); v[6] = cfmul(v[6], w6); v[7] = cfmul(v[7], w7); v[8] = cfmul(v[8], w8);
+    v[9] = cfmul(v[9], cfmul(w8, w)); v[10] = cfmul(v[10], cfmul(w8, w2)); v[11] = cfmul(v[11], cfmul(w8, w3));
+    v[12] = cfmul(v[12], cfmul(w8, w4)); v[13] = cfmul(v[13], cfmul(w8, w5)); v[14] = cfmul(v[14], cfmul(w8, w6));
+    v[15] = cfmul(v[15], cfmul(w8, w7));
+}
+
+// Forward complex FFT of 4096 points, 256 threads x 16 points, three radix-16 Stockham passes.
+// In: v[r] = z[t + 256 r].  Out: Z[t + 256 m] in v[scr_perm(m)].  P, Q: two 4096-point LDS buffers; the caller
+// guarantees nobody still reads P when this starts storing into it, and may use P again after the call returns
+// (every thread has passed the barrier that follows the stores into Q).
+GF3_DEV void scr_fft4096(cf (&v)[16], cf* P, cf* Q, cf tw2, cf tw3, int t) {
+    scr_dft16(v);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) P[t * 16 + (m ^ (t & 15))] = v[scr_perm(m)];       // logical t*16 + m, XOR-swizzled
+    lds_barrier();
+    {
+        const int ts = t ^ ((t >> 4) & 15);
+        cf x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = P[ts + 256 * r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = x[r];
+    }
+    scr_twiddle16(v, tw2);
+    scr_dft16(v);
+    {
+        const int k = t & 15, base = (t - k) * 16 + k;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) Q[base + 16 * m] = v[scr_perm(m)];
+    }
+    lds_barrier();
+    {
+        cf x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] = Q[t + 256 * r];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = x[r];
+    }
+    scr_twiddle16(v, tw3);
+    scr_dft16(v);
+}
+
+struct ScreenArgs {
+    const void* in; int64_t n_in; int dt;
+    const cf* tw;              // [4096] exp(-2 pi i m / 4096)
+    const cf* twn;             // [2049] exp(-2 pi i k / 8192)
+    const float4* Hs;          // [Q][8][256]: (H_q[k], H_q[4096 - k]), k = t + 256 r  (thread 0, r = 0: bin 2048 twice)
+    const float* H0N;          // [Q][2]: H_q[0], H_q[4096] (real)
+    const float* Hinf;         // [Q] max_k |H_q[k]|, rounded up
+    int Q, H, Lc;
+    int64_t nblk, plen;
+    float* P32;                // [plen]
+    float* blk_max;            // [nblk] max of the block's P32
+    float* blk_err;            // [nblk] bound on |P32 - P| for every lag of the block
+};
+
+// one window: samples -> spectrum slots.  X[2r] = X[k_r], X[2r+1] = X[4096 - k_r], k_r = t + 256 r (thread 0, r = 0:
+// both slots hold bin 2048); thread 0 also gets DC and Nyquist in z0 = (X[0], X[4096]).  Returns this thread's
+// share of the window's energy (sum of squares of the 32 samples it loaded).
+template <int DT>
+GF3_DEV float scr_window_spectrum(const ScreenArgs& a, int64_t seg, cf (&v)[16], cf& z0, cf* P, cf* Q, cf tw2, cf tw3, cf wb, int t) {
+    typedef typename RawT<DT>::E E;
+    // valid part of the window in window-relative sample numbers [lo, hi): 32-bit per-lane arithmetic from here on
+    const int lo = seg >= 0 ? 0 : (seg <= -(int64_t)(2 * GF3_SCR_NC) ? 2 * GF3_SCR_NC : (int)(-seg));
+    const int64_t rem = a.n_in - seg;
+    const int hi = rem >= 2 * GF3_SCR_NC ? 2 * GF3_SCR_NC : (rem <= 0 ? 0 : (int)rem);
+    float e2 = 0.0f;
+    if (lo == 0 && hi == 2 * GF3_SCR_NC) {              // (uniform) the whole window lies inside the stream
+        const E* base = (const E*)a.in + seg;
+        const unsigned t2 = 2u * (unsigned)t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            RawPair<DT> raw;
+            raw.load_u(base, t2 + 512u * (unsigned)r);
+            v[r] = cfmk((float)raw.v.a, (float)raw.v.b);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = 2 * (t + 256 * r);
+            float x0 = 0.0f, x1 = 0.0f;
+            if (j >= lo && j < hi) x0 = (float)((const E*)a.in)[seg + j];
+            if (j + 1 >= lo && j + 1 < hi) x1 = (float)((const E*)a.in)[seg + j + 1];
+            v[r] = cfmk(x0, x1);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) e2 = fmaf(v[r].x, v[r].x, fmaf(v[r].y, v[r].y, e2));
+    scr_fft4096(v, P, Q, tw2, tw3, t);
+    // exchange for the packed-real split: natural order into P (free: every thread is past the second barrier)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) P[t + 256 * m] = v[scr_perm(m)];
+    lds_barrier();
+    z0 = P[0];
+    const float c32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                          0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+    const float s32[8] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                          0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const bool self = (t == 0 && r == 0);
+        const int k = self ? GF3_SCR_NC / 2 : t + 256 * r;
+        const cf A = P[k], Bm = P[GF3_SCR_NC - k];
+        cf w = cfmul(wb, cfmk(c32[r], -s32[r]));                 // exp(-2 pi i (t + 256 r) / 8192)
+        if (self) w = cfmk(0.0f, -1.0f);
+        const cf Bc = cfconj(Bm);
+        const cf Ee = cfmk(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
+        const cf Dd = cfmk(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
+        const cf Ow = cfmul(cf_negi(Dd), w);
+        v[2 * r] = cfadd(Ee, Ow);                                // X[k]
+        v[2 * r + 1] = cfconj(cfsub(Ee, Ow));                    // X[4096 - k]
+    }
+    z0 = cfmk(z0.x + z0.y, z0.x - z0.y);
+    return e2;
+}
+
+template <int DT>
+__global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
+    extern __shared__ double2 smem[];
+    constexpr int NC = GF3_SCR_NC, T = GF3_SCR_T, B = GF3_SCR_B;
+    cf* bufA = (cf*)smem;
+    cf* bufB = bufA + NC;
+    float* nrm = (float*)(bufB + NC);                 // [32][4] per-window, per-wave energy
+    float* red = nrm + 128;                           // [B][4] per-block, per-wave maximum
+    const int t = threadIdx.x, wave = t >> 6;
+    const int64_t b0 = (int64_t)B * blockIdx.x;
+    cf tw2 = a.tw[(t & 15) * 16], tw3 = a.tw[t], wb = a.twn[t];
+    // Made opaque before every transform: otherwise LLVM hoists all 30 twiddle powers of the two passes and the
+    // eight split twiddles out of the window loop and keeps ~80 registers of them live across it.
+    auto refresh = [&]() {
+        asm volatile("" : "+v"(tw2.x), "+v"(tw2.y), "+v"(tw3.x), "+v"(tw3.y), "+v"(wb.x), "+v"(wb.y));
+    };
+    cf acc[B][16];
+    float dc[B], ny[B];
+#pragma unroll
+    for (int g = 0; g < B; ++g) {
+        dc[g] = ny[g] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc[g][s] = cfmk(0.0f, 0.0f);
+    }
+    const int nw = a.Q + B - 1;                       // windows b0 .. b0 + nw - 1
+    for (int w = 0; w < nw; ++w) {
+        cf v[16], z0;
+        cf* P = (w & 1) ? bufB : bufA;
+        cf* Qb = (w & 1) ? bufA : bufB;
+        const int64_t seg = (b0 + w) * (int64_t)a.H - (a.Lc - 1);
+        refresh();
+        float e2 = scr_window_spectrum<DT>(a, seg, v, z0, P, Qb, tw2, tw3, wb, t);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) e2 += __shfl_xor(e2, d, 64);
+        if ((t & 63) == 0) nrm[w * 4 + wave] = e2;
+#pragma unroll
+        for (int g = 0; g < B; ++g) {
+            const int h = w - g;
+            if (h >= 0 && h < a.Q) {
+                const float4* Hp = a.Hs + ((int64_t)h * 8) * T + t;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float4 hh = Hp[r * T];
+                    acc[g][2 * r] = cf_fma_conj(v[2 * r], cfmk(hh.x, hh.y), acc[g][2 * r]);
+                    acc[g][2 * r + 1] = cf_fma_conj(v[2 * r + 1], cfmk(hh.z, hh.w), acc[g][2 * r + 1]);
+                }
+                if (t == 0) { dc[g] = fmaf(z0.x, a.H0N[2 * h], dc[g]); ny[g] = fmaf(z0.y, a.H0N[2 * h + 1], ny[g]); }
+                asm volatile("" ::: "memory");        // one block's eight spectrum loads in flight at a time (32 registers, not 32 B)
+            }
+        }
+    }
+    // ---- per block: inverse real FFT of the Hermitian spectrum, store, maximum
+    const float inv = 1.0f / (float)NC;
+    const float c32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                          0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+    const float s32[8] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                          0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f};
+#pragma unroll
+    for (int g = 0; g < B; ++g) {
+        const int64_t m0 = (b0 + g) * (int64_t)a.H;
+        if (m0 < a.plen) {                             // (uniform)
+            lds_barrier();                             // everyone is done with both buffers
+            refresh();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const bool self = (t == 0 && r == 0);
+                const int k = self ? NC / 2 : t + 256 * r;
+                cf w = cfmul(wb, cfmk(c32[r], -s32[r]));
+                if (self) w = cfmk(0.0f, -1.0f);
+                const cf A = acc[g][2 * r], Bc = cfconj(acc[g][2 * r + 1]);
+                const cf Ee = cfmk(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
+                const cf Dd = cfmk(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
+                const cf Op = cfmul(Dd, cfconj(w));                         // * exp(+2 pi i k / 8192)
+                const cf Zk = cfadd(Ee, cf_posi(Op));
+                const cf Zm = cfadd(cfconj(Ee), cf_posi(cfconj(Op)));
+                bufA[k] = cfconj(Zk);
+                if (!self) bufA[NC - k] = cfconj(Zm);
+            }
+            if (t == 0) bufA[0] = cfmk(0.5f * (dc[g] + ny[g]), -0.5f * (dc[g] - ny[g]));      // conj(E + i Op)
+            lds_barrier();
+            cf v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = bufA[t + 256 * r];
+            scr_fft4096(v, bufB, bufA, tw2, tw3, t);  // (stores into bufA only after its first barrier: every thread has read its inputs by then)
+            // z = conj(FFT(conj Z)) / NC ; y[2n] = Re z, y[2n+1] = Im z, n = t + 256 m
+            const int64_t left = a.plen - m0;
+            const int W = left < a.H ? (int)left : a.H;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const int i = 2 * (t + 256 * m);
+                const cf z = v[scr_perm(m)];
+                const float y0 = z.x * inv, y1 = -z.y * inv;
+                if (i + 1 < W) {
+                    *(float2*)(a.P32 + m0 + i) = make_float2(y0, y1);
+                    mx = fmaxf(mx, fmaxf(y0, y1));
+                } else if (i < W) {
+                    a.P32[m0 + i] = y0;
+                    mx = fmaxf(mx, y0);
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            if ((t & 63) == 0) red[g * 4 + wave] = mx;
+        }
+    }
+    lds_barrier();
+    if (t < B) {
+        const int64_t blk = b0 + t;
+        if (blk < a.nblk) {
+            a.blk_max[blk] = fmaxf(fmaxf(red[t * 4], red[t * 4 + 1]), fmaxf(red[t * 4 + 2], red[t * 4 + 3]));
+            float e = 0.0f;
+            for (int q = 0; q < a.Q; ++q) {
+                const float* n4 = nrm + (t + q) * 4;
+                const float n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
+                e = fmaf(a.Hinf[q], sqrtf(n2) * 1.0001f, e);
+            }
+            a.blk_err[blk] = e * GF3_SCR_GAMMA * 1.0001f + 1e-37f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- screening bookkeeping
+struct ScrMisc {                  // device-resident scalars of one gf3_sync_stream call
+    double Mlo;                   // best lower bound of the maximum: max_b (blk_max - blk_err)
+    double M;                     // the maximum (fp64 re-evaluation)
+    double lim;                   // lags whose upper bound stays below this cannot pass the threshold
+    long long ncellA, ncellB;     // cells listed for the maximum / for the candidates
+    long long status;             // bit 0: a work list overflowed -> the caller falls back to the all-fp64 path
+};
+
+__global__ void scr_mlo_kernel(const float* blk_max, const float* blk_err, int64_t nblk, ScrMisc* misc) {
+    __shared__ double scratch[16];
+    double m = -INFINITY;
+    for (int64_t i = threadIdx.x; i < nblk; i += blockDim.x) m = fmax(m, (double)blk_max[i] - (double)blk_err[i]);
+    m = block_max(m, scratch);
+    if (threadIdx.x == 0) { misc->Mlo = m; misc->status = 0; misc->ncellA = misc->ncellB = 0; }
+}
+
+// Cells: cell c = centre lags m = 1 + 14 c .. 14 + 14 c of the full correlation (zeros-indices i = m - 1); its
+// refinement evaluates the 16 lags 14 c .. 14 c + 15.  A cell is listed when one of its lags (centres, plus lag 0
+// for cell 0 and the last lag for the last cell) has an upper bound P32 + E_b that reaches `level`.
+// pass 0 counts the listed cells per workgroup, pass 1 writes their numbers in ascending order.
+#define SCR_LIST_THREADS 256
+__global__ __launch_bounds__(SCR_LIST_THREADS) void scr_cells_kernel(const float* __restrict__ P32, const float* __restrict__ blk_max,
+                                                                     const float* __restrict__ blk_err, int H, int64_t plen, int64_t ncell,
+                                                                     const ScrMisc* misc, int which, int64_t* counts,
+                                                                     const int64_t* offsets, int64_t* cells, int64_t cap) {
+    __shared__ int wsum[SCR_LIST_THREADS / 64];
+    if (misc->status & 1) { if (!offsets && threadIdx.x == 0) counts[blockIdx.x] = 0; return; }
+    if (offsets && counts[blockIdx.x] == 0) return;
+    const double level = which == 0 ? misc->Mlo : misc->lim;
+    const int64_t c0 = (int64_t)blockIdx.x * SCR_LIST_THREADS;
+    // blocks touched by this workgroup's lags [14 c0, 14 (c0 + 256) + 2): skip everything when none can reach the level
+    if (!offsets) {
+        const int64_t mlo = GF3_SCR_CELL * c0, mhi = GF3_SCR_CELL * (c0 + SCR_LIST_THREADS) + 2;
+        bool any = false;
+        for (int64_t b = mlo / H; b <= (mhi - 1) / H && b * (int64_t)H < plen; ++b)
+            any = any || ((double)blk_max[b] + (double)blk_err[b] >= level) || !(level == level);
+        if (!any) { if (threadIdx.x == 0) counts[blockIdx.x] = 0; return; }
+    }
+    const int64_t c = c0 + threadIdx.x;
+    bool hit = false;
+    if (c < ncell) {
+        int64_t lo = GF3_SCR_CELL * c + 1, hi = lo + GF3_SCR_CELL;           // centres [lo, hi)
+        if (c == 0) lo = 0;
+        if (c == ncell - 1) hi = plen;
+        if (hi > plen) hi = plen;
+        for (int64_t m = lo; m < hi; ++m) {
+            const double up = (double)P32[m] + (double)blk_err[m / H];
+            hit = hit || (up >= level) || !(up == up);                      // (a NaN anywhere keeps the lag)
+        }
+        hit = hit || !(level == level);
+    }
+    const unsigned long long bal = __ballot(hit);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < SCR_LIST_THREADS / 64; ++w) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+    if (!offsets) { if (threadIdx.x == 0) counts[blockIdx.x] = total; return; }
+    if (hit) {
+        const int64_t o = offsets[blockIdx.x] + woff + __popcll(bal & ((1ull << lane) - 1ull));
+        if (o < cap) cells[o] = c;
+    }
+}
+
+// total of a cell list -> misc, overflow -> status
+__global__ void scr_total_kernel(const int64_t* total, int64_t cap, ScrMisc* misc, int which) {
+    const long long n = total[0];
+    if (which == 0) misc->ncellA = n; else misc->ncellB = n;
+    if (n > cap) misc->status |= 1;
+}
+
+// fp64 re-evaluation of the 16 lags of one cell: P[m] = sum_k r[m - Lc + 1 + k] c[k], m = 14 c + j, j = 0..15.
+// Each thread takes a contiguous range of taps and slides a 31-sample window over them, 16 taps at a time
+// (256 fma per 31 sample loads + 16 tap loads); the 16 partial sums are then reduced over the workgroup.
+struct RefineArgs {
+    const void* in; int64_t n_in; int dt;
+    const double* chirp; int Lc;
+    const int64_t* cells; const ScrMisc* misc; int which;     // which = 0: maximum, 1: candidates
+    int64_t plen, nz; double thresh;
+    double* cell_max;             // which = 0: [ncellA] max of the cell's fp64 lags
+    unsigned* cell_mask;          // which = 1: [ncellB] bit j: zeros-index 14 c + j is a candidate
+    int64_t* cell_cnt;            // which = 1: [ncellB] popcount of the mask (for the ordered compaction)
+    double* dbg;                  // optional [ncell][16] fp64 values (tests)
+};
+#define SCR_REF_THREADS 256
+template <int DT>
+__global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_kernel(RefineArgs a) {
+    __shared__ double part[SCR_REF_THREADS / 64][16];
+    __shared__ double P[16];
+    typedef typename RawT<DT>::E E;
+    if (a.misc->status & 1) return;
+    const long long ncell = a.which == 0 ? a.misc->ncellA : a.misc->ncellB;
+    const int t = threadIdx.x;
+    const int per = (a.Lc + SCR_REF_THREADS - 1) / SCR_REF_THREADS;
+    const int k_lo = t * per, k_hi = min(a.Lc, k_lo + per);
+    // the grid is fixed (the list length lives on the device): each workgroup takes every gridDim.x-th cell
+    for (long long ci = blockIdx.x; ci < ncell; ci += gridDim.x) {
+        const int64_t c = a.cells[ci];
+        const int64_t m0 = GF3_SCR_CELL * c;
+        const int64_t s0 = m0 - (a.Lc - 1);            // sample index of tap 0 for lag m0
+        double acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+        for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+            double x[31];
+            const int64_t i0 = s0 + k0;
+            if (i0 >= 0 && i0 + 31 <= a.n_in) {
+#pragma unroll
+                for (int i = 0; i < 31; ++i) x[i] = (double)((const E*)a.in)[i0 + i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 31; ++i) x[i] = (i0 + i >= 0 && i0 + i < a.n_in) ? (double)((const E*)a.in)[i0 + i] : 0.0;
+            }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const double ck = (k0 + kk < k_hi) ? a.chirp[k0 + kk] : 0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fma(ck, x[kk + j], acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double s = acc[j];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+            acc[j] = s;
+        }
+        __syncthreads();                               // the previous cell's P[] and part[] have been consumed
+        if ((t & 63) == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) part[t >> 6][j] = acc[j];
+        }
+        __syncthreads();
+        if (t < 16) {
+            double s = 0.0;
+            for (int w = 0; w < SCR_REF_THREADS / 64; ++w) s += part[w][t];
+            P[t] = s;
+            if (a.dbg) a.dbg[ci * 16 + t] = s;
+        }
+        __syncthreads();
+        if (a.which == 0) {
+            if (t == 0) {
+                double mx = -INFINITY;
+                bool nan = false;
+                for (int j = 0; j < 16; ++j) if (m0 + j < a.plen) { mx = fmax(mx, P[j]); nan = nan || !(P[j] == P[j]); }
+                a.cell_max[ci] = nan ? NAN : mx;
+            }
+            continue;
+        }
+        // candidates: the reference's rule on the fp64 values, division by the maximum first (OFDM.py:359-361)
+        bool cand = false;
+        if (t < GF3_SCR_CELL) {
+            const int64_t i = m0 + t;
+            if (i < a.nz) {
+                const double M = a.misc->M;
+                const double p0 = P[t] / M, p1 = P[t + 1] / M, p2 = P[t + 2] / M;
+                cand = ((p1 - p0) * (p2 - p1) <= 0.0) && (p1 > a.thresh);
+            }
+        }
+        const unsigned long long bal = __ballot(cand);
+        if (t == 0) {
+            a.cell_mask[ci] = (unsigned)(bal & 0x3fffull);
+            a.cell_cnt[ci] = __popcll(bal & 0x3fffull);
+        }
+    }
+}
+
+// maximum over the re-evaluated cells -> misc->M and the screening limit for the candidates
+__global__ void scr_max_kernel(const double* cell_max, ScrMisc* misc, double thresh) {
+    __shared__ double scratch[16];
+    if (misc->status & 1) return;
+    double m = -INFINITY;
+    const long long n = misc->ncellA;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, cell_max[i]);
+    bool nan = false;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) nan = nan || !(cell_max[i] == cell_max[i]);
+    m = block_max(m, scratch);
+    const int anynan = __syncthreads_or(nan ? 1 : 0);
+    if (threadIdx.x == 0) {
+        if (anynan) m = NAN;                                          // np.amax propagates NaN
+        misc->M = m;
+        const bool filt = m > 0.0 && thresh > 0.0 && m < INFINITY && thresh < INFINITY;
+        misc->lim = filt ? thresh * m * (1.0 - 1e-6) : -INFINITY;     // same prefilter as pk_candidates
+    }
+}
+
+// ordered expansion of the cell masks into zeros-indices
+__global__ void scr_expand_kernel(const int64_t* cells, const unsigned* cell_mask, const int64_t* offsets, const ScrMisc* misc,
+                                  int64_t* cand, int64_t cap) {
+    if (misc->status & 1) return;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= misc->ncellB) return;
+    unsigned m = cell_mask[i];
+    int64_t o = offsets[i];
+    const int64_t base = GF3_SCR_CELL * cells[i];
+    while (m) {
+        const int j = __ffs((int)m) - 1;
+        if (o < cap) cand[o] = base + j;
+        ++o;
+        m &= m - 1;
+    }
+}

@@ -267,6 +267,31 @@ class Engine:
         peaks = peaks[: cnt.value]
         return (peaks, corr) if want_corr else peaks
 
+    def sync_stream_mode(self, mode):
+        """0 (default): fp32 screening + fp64 decisions, all-fp64 when the screen is not selective or P is asked for;
+        1: always the all-fp64 overlap-save path (gf3_sync_stream_mode)."""
+        self._check(self.lib.gf3_sync_stream_mode(self._h, int(mode)))
+
+    def sync_stream_info(self):
+        """Of the last sync_stream call: dict(path=0 screened | 1 fp64 after a non-selective screen | 2 fp64,
+        cells_max, cells_cand, candidates)."""
+        out = (C.c_int64 * 4)()
+        self._check(self.lib.gf3_sync_stream_info(self._h, out))
+        return dict(path=int(out[0]), cells_max=int(out[1]), cells_cand=int(out[2]), candidates=int(out[3]))
+
+    def debug_stream_screen(self, x):
+        """The fp32 screening pass alone (tests): (P32 [n+Lc-1] float32, block maxima, block error bounds, hop)."""
+        x = self._samples(x).reshape(-1)
+        n = x.numel()
+        plen = n + self.cfg.chirp_length - 1
+        p32 = self._new((plen,), torch.float32)
+        nb_max = plen // 16 + 2                                  # (hop >= 16: more than enough room)
+        blk = self._new((2 * nb_max,), torch.float32)
+        hop = C.c_int32(0)
+        self._check(self.lib.gf3_debug_stream_screen(self._h, _ptr(x), n, _ptr(p32), _ptr(blk), C.byref(hop), self._stream()))
+        nblk = -(-plen // hop.value)
+        return p32, blk[:nblk], blk[nblk: 2 * nblk], hop.value
+
     def tx_frames(self, bits_packed, filler, stride=None, gaps=None, out_dtype=torch.float32):
         """Synthesise chirp-prefixed packets (transmit side of the reference, OFDM.py:196-259).
         bits_packed: uint8 [F, bytes_per_frame] (the format demod_frames writes); filler: complex [K],

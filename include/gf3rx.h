@@ -164,6 +164,22 @@ int gf3_sync_stream(gf3_ctx *ctx, const void *d_r, int64_t n,
                     void *d_work, double *d_corr_or_null, void *stream);
 
 /*
+ * How gf3_sync_stream evaluates the matched filter.  mode 0 (default): every lag is first evaluated in fp32 with a
+ * proven error bound; only the lags that the bound cannot exclude (a few around every chirp) are re-evaluated as fp64
+ * dot products, and the reference's rule (global maximum, threshold, extremum test) is applied to those fp64 values --
+ * no decision rests on an fp32 number; streams on which the screen is not selective, and calls that ask for d_corr,
+ * take the all-fp64 overlap-save path.  mode 1: always the all-fp64 path.
+ */
+int gf3_sync_stream_mode(gf3_ctx *ctx, int32_t mode);
+/* h_out4 (host): of the last gf3_sync_stream call: path (0 screened, 1 fp64 after a non-selective screen, 2 fp64),
+ * cells re-evaluated for the maximum, cells re-evaluated for candidates, candidates found */
+int gf3_sync_stream_info(const gf3_ctx *ctx, int64_t *h_out4);
+/* tests: the fp32 screening pass alone.  d_p32 [n+Lc-1] float; d_blk [2*nblk] float: per block of *h_hop lags its
+ * maximum, then the bound on |P32 - P| of its lags (nblk = ceil((n+Lc-1) / hop)) */
+int gf3_debug_stream_screen(gf3_ctx *ctx, const void *d_r, int64_t n, float *d_p32, float *d_blk,
+                            int32_t *h_hop, void *stream);
+
+/*
  * receiver.schmidlcox_method (OFDM.py:376-387; unused by receive()): running-sum
  * autocorrelation metric P[d+1] = P[d] + r[d+L] r[d+2L] - r[d] r[d+L] (L = K+1) over search_len lags;
  * *d_index (device int64) = first index of max |P| + N - 1.  Needs n >= search_len - 1 + 2L samples.

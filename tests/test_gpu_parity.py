@@ -414,9 +414,14 @@ def test_config3_full_size_stream():
     want_peaks = np.flatnonzero(orc.pick_peaks(Pfull, p.Lc, len(rh), p.thresh))
     del Pfull
     got_peaks = eng.sync_stream(r).cpu().numpy()
+    info = eng.sync_stream_info()
+    assert info["path"] == 0 and info["cells_cand"] < 8 * (F + 1), info      # fp32 screen + fp64 decisions, a few cells per chirp
     assert len(want_peaks) == F + 1
     assert np.array_equal(got_peaks, want_peaks)
     assert np.array_equal(starts.cpu().numpy(), want_peaks[:-1] + 2)
+    eng.sync_stream_mode(1)                                                   # and the all-fp64 path agrees
+    assert np.array_equal(eng.sync_stream(r).cpu().numpy(), want_peaks)
+    eng.sync_stream_mode(0)
     # ---- demod: 256 random packets + the 16 worst, each cut out with some margin and fed to the oracle
     rs = np.random.RandomState(2026)
     pick = np.unique(np.concatenate([rs.choice(F, 256, replace=False), np.asarray(res["worst_packets"]), [0, F - 1]]))
@@ -735,3 +740,89 @@ def test_constant_streams_make_every_lag_a_candidate(dt, level, n_chirps):
     assert ncand > 0.25 * len(P)
     ref = orc.matched_filter(np.full(n, float(level)), p)
     assert np.abs(P - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def _screen_cases():
+    g1, g2 = load("g1_n1024_qpsk"), load("g2_n4096_qpsk")
+    rs = np.random.RandomState(77)
+    spike = np.zeros(60000); spike[31234] = 1e6; spike[5] = -3e5                       # energy in two samples
+    return [("g1", params_of(g1), g1["r"], torch.float64), ("g2", params_of(g2), g2["r"], torch.float64),
+            ("g2_f32", params_of(g2), g2["r"].astype(np.float32), torch.float32),
+            ("noise", params_of(g1), rs.randn(150000), torch.float64),
+            ("u8_dc", params_of(g1), np.clip(np.round(128 + 20 * rs.randn(90000)), 0, 255).astype(np.uint8), torch.uint8),
+            ("ramp_i16", params_of(g1), (np.arange(70000) % 30000 - 15000).astype(np.int16), torch.int16),
+            ("spike", params_of(g1), spike, torch.float64),
+            ("ones", params_of(g1), np.ones(40000), torch.float64)]
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_stream_screen_error_bound_holds(case):
+    """The fp32 screening pass of gf3_sync_stream (gf3rx_screen.h) against the oracle's fp64 matched filter: on every
+    lag |P32 - P| must stay below the block's bound E_b -- that is what makes the screen safe -- and the realised
+    error must be far inside it (the bound uses 256 u per partition; the arithmetic delivers a few u)."""
+    name, p, r, dt = _screen_cases()[case]
+    eng = engine_for(p, in_dtype=dt)
+    x = torch.from_numpy(np.ascontiguousarray(r)).cuda()
+    p32, bmax, berr, hop = eng.debug_stream_screen(x)
+    P = orc.matched_filter(np.asarray(r, dtype=np.float64), p)
+    p32 = p32.cpu().numpy().astype(np.float64); berr = berr.cpu().numpy().astype(np.float64); bmax = bmax.cpu().numpy()
+    assert len(p32) == len(P) and hop % 2 == 0
+    err = np.abs(p32 - P)
+    per_lag = np.repeat(berr, hop)[: len(P)]
+    assert (err <= per_lag).all(), (name, float((err / per_lag).max()))
+    assert (err / np.maximum(per_lag, 1e-300)).max() < 0.125, (name, float((err / per_lag).max()))
+    nb = len(berr)
+    want_max = np.array([p32[b * hop: (b + 1) * hop].max() for b in range(nb)])
+    assert np.array_equal(bmax.astype(np.float64), want_max)
+
+
+@pytest.mark.parametrize("name", LOOPBACKS)
+def test_stream_sync_screened_equals_fp64_path(name):
+    """Both evaluations of chirp_method -- fp32 screen + fp64 decisions (default) and all-fp64 overlap-save -- return
+    the reference fixture's peaks, on f64, f32 and PCM storage; the screened call re-evaluates only a few cells."""
+    g = load(name)
+    p = params_of(g)
+    r = g["r"]
+    for dt, rq in ((torch.float64, r), (torch.float32, r.astype(np.float32)),
+                   (torch.int16, np.round(r / np.abs(r).max() * 30000).astype(np.int16))):
+        eng = engine_for(p, in_dtype=dt)
+        x = torch.from_numpy(rq).cuda()
+        want = np.flatnonzero(orc.chirp_method(rq.astype(np.float64), p))
+        if dt == torch.float64:
+            assert np.array_equal(want, g["peaks"])
+        got = eng.sync_stream(x).cpu().numpy()
+        info = eng.sync_stream_info()
+        assert np.array_equal(got, want)
+        assert info["path"] == 0 and 0 < info["cells_max"] <= 64 and info["cells_cand"] <= 64 * len(want), info
+        eng.sync_stream_mode(1)
+        assert np.array_equal(eng.sync_stream(x).cpu().numpy(), want)
+        assert eng.sync_stream_info()["path"] == 2
+        eng.sync_stream_mode(0)
+        peaks, corr = eng.sync_stream(x, want_corr=True)                    # asking for P takes the fp64 path
+        assert eng.sync_stream_info()["path"] == 2 and np.array_equal(peaks.cpu().numpy(), want)
+
+
+def test_stream_sync_falls_back_when_the_screen_is_not_selective():
+    """Noise with a low threshold: nearly every cell would have to be re-evaluated, the work list overflows and the
+    call transparently takes the all-fp64 path (path 1); the peaks are the oracle's either way."""
+    import dataclasses
+    g = load("g1_n1024_qpsk")
+    p = dataclasses.replace(params_of(g), thresh=0.1)
+    rs = np.random.RandomState(5)
+    n = 400_000
+    r = 0.05 * rs.randn(n)
+    c = orc.chirp_replica(p)
+    for pos in (3000, 120_000, 250_000, n - 500 - p.Lc):
+        r[pos: pos + p.Lc] += 0.008 * c / np.abs(c).max()
+    eng = engine_for(p, thresh=p.thresh)
+    x = torch.from_numpy(r).cuda()
+    got = eng.sync_stream(x, cap=4096).cpu().numpy()
+    assert eng.sync_stream_info()["path"] == 1
+    assert np.array_equal(got, np.flatnonzero(orc.chirp_method(r, p)))
+    # the same stream with the chirps well above the noise: selective again
+    r2 = 0.0005 * rs.randn(n)
+    for pos in (3000, 120_000, 250_000, n - 500 - p.Lc):
+        r2[pos: pos + p.Lc] += c
+    got2 = eng.sync_stream(torch.from_numpy(r2).cuda(), cap=4096).cpu().numpy()
+    assert eng.sync_stream_info()["path"] == 0
+    assert np.array_equal(got2, np.flatnonzero(orc.chirp_method(r2, p)))
