@@ -224,9 +224,11 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     // LDS: [scratch 32 doubles | start-up rotation tables | FFT buffer | decision bytes | (fit-range overflow)]
     double* scratch = (double*)smem;
     cplx* rtab = (cplx*)(scratch + 32);                                   // [2][64 + NC/64 + 1]
-    double2* mags = (double2*)(rtab + 2 * (64 + NC / 64 + 1));            // [8][T] (a0, da) of slot s of thread t (table modes)
-    cplx* lds = (cplx*)(mags + DemodOcc<NC, MODE>::MAG_ELEMS);            // FFT buffer, DemodOcc::LDS_ELEMS points
+    cplx* lds = rtab + 2 * (64 + NC / 64 + 1);                            // FFT buffer, DemodOcc::LDS_ELEMS points
     uint8_t* labs = (uint8_t*)(lds + DemodOcc<NC, MODE>::LDS_ELEMS);      // [ring][C] decisions, one byte each
+    // [8][T] (a0, da) of slot s of thread t (table modes), behind the decision bytes: written only after the
+    // channel-estimate stage, whose fit-range arrays may run over this region
+    double2* mags = (double2*)(labs + ((a.ring * a.C + 15) & ~15));
     const int tid = threadIdx.x;
     const int64_t f = blockIdx.x;
     const int K = a.K, P = a.P, D = a.D, S = a.S;
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     cplx* hsl = lds;
     cplx* hel = hsl + L;                              // [L] same for He
     cplx u[8];
+    double a0[8], da[8];                              // (table modes; parked in LDS once the fit is done)
     // The transforms of this kernel leave 2 X in the slots (rfft_regs<.., TWICE>): XS is that factor (1 when the
     // spectra come from memory).  It is divided out of the pilots here and carried by the magnitudes a0, da, so the
     // channel estimates are true-scale and X/Hest is unchanged -- bit for bit, powers of two being exact.
@@ -354,7 +357,8 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         if constexpr (MODE != MODE_QPSK) {
             const double e2 = He[s].x * He[s].x + He[s].y * He[s].y;
             const double ah = m2 * ia;                                // |Hs|
-            mags[s * T + tid] = make_double2(XS * ah, XS * (e2 * rsq_nr(e2) - ah));   // XS |Hs|, XS (|He| - |Hs|)
+            a0[s] = XS * ah;
+            da[s] = XS * (e2 * rsq_nr(e2) - ah);                      // XS (|He| - |Hs|)
         }
         u[s] = cmk(Hs[s].x * ia, Hs[s].y * ia);
     }
@@ -393,6 +397,10 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     }
     if (tid == 0 && a.slope) a.slope[f] = slope;
     GF3_STAMP(3);
+    if constexpr (DemodOcc<NC, MODE>::MAG_LDS) {      // (block_sum's barriers: every thread is done with the fit-range arrays)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) mags[s * T + tid] = make_double2(a0[s], da[s]);
+    }
 
     // ---- data symbols: FFT -> /Hest -> demap -> bit-pack (OFDM.py:466-478, 487-505)
     // Decisions are staged as one byte per data carrier in a ring of `ring` symbols in LDS and
@@ -915,10 +923,12 @@ __global__ void pk_candidates(const double* __restrict__ P, int64_t nz, const do
     for (int k = 0; k < PK_ITEMS; ++k) if (flags & (1u << k)) cand[o++] = base + k;
 }
 #define SCAN_PER 16
-__global__ void pk_scan(const int64_t* counts, int64_t n, int64_t* offsets, int64_t* total) {
+// n_dev (optional, device): scan only the first min(n, *n_dev) counts -- lists whose length lives on the device
+__global__ void pk_scan(const int64_t* counts, int64_t n, int64_t* offsets, int64_t* total, const long long* n_dev = nullptr) {
     // one workgroup, exclusive scan; each thread owns SCAN_PER consecutive counts per step
     __shared__ int64_t wsum[16];
     __shared__ int64_t carry;
+    if (n_dev && (int64_t)n_dev[0] < n) n = n_dev[0] < 0 ? 0 : (int64_t)n_dev[0];
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -1688,16 +1698,16 @@ static int demod_ring(const gf3_ctx* c) {
     while (r < need) r <<= 1;
     return r;
 }
-// lean = MODE_QPSK (ping-pong FFT buffers); the table modes use the in-place buffer and, ahead of it, NC (a0, da) pairs.
-// Layout: [scratch 32 doubles | rotation tables | (a0, da) pairs | FFT buffer | decision bytes], the last two overlaid
-// by Hs, He of the fit range during the channel-estimate stage (which may need more than they hold).
+// lean = MODE_QPSK (ping-pong FFT buffers); the table modes use the in-place buffer and NC (a0, da) pairs.
+// Layout: [scratch 32 doubles | rotation tables | FFT buffer | decision bytes | (a0, da) pairs]; everything from the
+// FFT buffer on is overlaid by Hs, He of the fit range during the channel-estimate stage (which may need more).
 static size_t demod_lds_bytes(const gf3_ctx* c, bool lean = false) {
     const bool inplace = !lean || (GF3_DEMOD_WPS > 2 && c->NC <= 2048);
     const size_t fft = inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC);
     const size_t mags = lean ? 0 : (size_t)c->NC * sizeof(double2);
-    const size_t tail = fft + (size_t)((demod_ring(c) * c->cfg.C + 15) & ~15);
+    const size_t tail = fft + (size_t)((demod_ring(c) * c->cfg.C + 15) & ~15) + mags;
     const size_t fit = (size_t)2 * (c->fit_hi - c->fit_lo) * sizeof(cplx);
-    return 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) + mags + (fit > tail ? fit : tail);
+    return 32 * sizeof(double) + (size_t)2 * (64 + c->NC / 64 + 1) * sizeof(cplx) + (fit > tail ? fit : tail);
 }
 
 extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,
@@ -1955,7 +1965,7 @@ static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
         w.s_ncell = (w.nz + GF3_SCR_CELL - 1) / GF3_SCR_CELL;
         if (w.s_ncell < 1) w.s_ncell = 1;
         w.s_nwg = (w.s_ncell + SCR_LIST_THREADS - 1) / SCR_LIST_THREADS;
-        w.s_capA = 4096;
+        w.s_capA = 4096 + 4 * (n / (c->Lc > 0 ? c->Lc : 1) + 1);   // every chirp of a clean stream peaks within the bound of the maximum
         w.s_capB = w.s_ncell / 16 > 4096 ? w.s_ncell / 16 : 4096;
         w.o_sblk = take((size_t)w.s_nblk * 8);                 // blk_max | blk_err (float each)
         w.o_smisc = take(sizeof(ScrMisc));
@@ -2012,7 +2022,7 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
         hipLaunchKernelGGL(scr_cells_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
                            (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, which, cnt, (const int64_t*)nullptr,
                            (int64_t*)nullptr, (int64_t)0);
-        hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.s_nwg, offs, total);
+        hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.s_nwg, offs, total, (const long long*)nullptr);
         hipLaunchKernelGGL(scr_total_kernel, dim3(1), dim3(1), 0, st, (const int64_t*)total, capc, misc, which);
         hipLaunchKernelGGL(scr_cells_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
                            (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, which, cnt, (const int64_t*)offs,
@@ -2031,11 +2041,11 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
     HIPCHK(c, refine(0, cellA, w.s_capA));
     hipLaunchKernelGGL(scr_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)cmaxA, misc, c->cfg.thresh);
     list_cells(1, cellB, w.s_capB);
-    HIPCHK(c, hipMemsetAsync(cntB, 0, (size_t)w.s_capB * 8, st));      // cells beyond the listed count contribute nothing
     HIPCHK(c, refine(1, cellB, w.s_capB));
-    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cntB, w.s_capB, offB, total);
+    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cntB, w.s_capB, offB, total, (const long long*)&misc->ncellB);
     hipLaunchKernelGGL(scr_expand_kernel, dim3((unsigned)((w.s_capB + 255) / 256)), dim3(256), 0, st, (const int64_t*)cellB, (const unsigned*)maskB,
                        (const int64_t*)offB, (const ScrMisc*)misc, cand, w.nz + 2);
+    hipLaunchKernelGGL(scr_guard_kernel, dim3(1), dim3(1), 0, st, (const ScrMisc*)misc, total);
     hipLaunchKernelGGL(pk_nms, dim3(1), dim3(NMS_THREADS), 0, st, (const int64_t*)cand, (const int64_t*)total,
                        (int64_t)c->Lc, w.nz, d_peaks, cap, np);
     HIPCHK(c, hipGetLastError());
@@ -2129,7 +2139,7 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     hipLaunchKernelGGL(pk_max_final, dim3(1), dim3(256), 0, st, (const double*)part, (int)w.nb_max, mx);
     hipLaunchKernelGGL(pk_candidates, dim3((unsigned)w.nb_c), dim3(PK_THREADS), 0, st, (const double*)P, w.nz,
                        (const double*)mx, c->cfg.thresh, cnt, (const int64_t*)nullptr, (int64_t*)nullptr);
-    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.nb_c, offs, total);
+    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.nb_c, offs, total, (const long long*)nullptr);
     hipLaunchKernelGGL(pk_candidates, dim3((unsigned)w.nb_c), dim3(PK_THREADS), 0, st, (const double*)P, w.nz,
                        (const double*)mx, c->cfg.thresh, cnt, (const int64_t*)offs, cand);
     hipLaunchKernelGGL(pk_nms, dim3(1), dim3(NMS_THREADS), 0, st, (const int64_t*)cand, (const int64_t*)total,

@@ -171,13 +171,13 @@ GF3_DEV float scr_window_spectrum(const ScreenArgs& a, int64_t seg, cf (&v)[16],
         cf w = cfmul(wb, cfmk(c32[r], -s32[r]));                 // exp(-2 pi i (t + 256 r) / 8192)
         if (self) w = cfmk(0.0f, -1.0f);
         const cf Bc = cfconj(Bm);
-        const cf Ee = cfmk(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
-        const cf Dd = cfmk(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
+        // (the halvings of E and D are dropped: the slots hold 2 X, undone -- exactly, a power of two -- by `inv` below)
+        const cf Ee = cfadd(A, Bc), Dd = cfsub(A, Bc);
         const cf Ow = cfmul(cf_negi(Dd), w);
-        v[2 * r] = cfadd(Ee, Ow);                                // X[k]
-        v[2 * r + 1] = cfconj(cfsub(Ee, Ow));                    // X[4096 - k]
+        v[2 * r] = cfadd(Ee, Ow);                                // 2 X[k]
+        v[2 * r + 1] = cfconj(cfsub(Ee, Ow));                    // 2 X[4096 - k]
     }
-    z0 = cfmk(z0.x + z0.y, z0.x - z0.y);
+    z0 = cfmk(2.0f * (z0.x + z0.y), 2.0f * (z0.x - z0.y));     // 2 X[0], 2 X[4096]
     return e2;
 }
 
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
         }
     }
     // ---- per block: inverse real FFT of the Hermitian spectrum, store, maximum
-    const float inv = 1.0f / (float)NC;
+    const float inv = 0.25f / (float)NC;              // 1/NC of the inverse transform, 1/2 of each of the two splits
     const float c32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
                           0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
     const float s32[8] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
@@ -251,15 +251,14 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
                 cf w = cfmul(wb, cfmk(c32[r], -s32[r]));
                 if (self) w = cfmk(0.0f, -1.0f);
                 const cf A = acc[g][2 * r], Bc = cfconj(acc[g][2 * r + 1]);
-                const cf Ee = cfmk(0.5f * (A.x + Bc.x), 0.5f * (A.y + Bc.y));
-                const cf Dd = cfmk(0.5f * (A.x - Bc.x), 0.5f * (A.y - Bc.y));
+                const cf Ee = cfadd(A, Bc), Dd = cfsub(A, Bc);              // (halvings folded into `inv` as well)
                 const cf Op = cfmul(Dd, cfconj(w));                         // * exp(+2 pi i k / 8192)
                 const cf Zk = cfadd(Ee, cf_posi(Op));
                 const cf Zm = cfadd(cfconj(Ee), cf_posi(cfconj(Op)));
                 bufA[k] = cfconj(Zk);
                 if (!self) bufA[NC - k] = cfconj(Zm);
             }
-            if (t == 0) bufA[0] = cfmk(0.5f * (dc[g] + ny[g]), -0.5f * (dc[g] - ny[g]));      // conj(E + i Op)
+            if (t == 0) bufA[0] = cfmk(dc[g] + ny[g], -(dc[g] - ny[g]));                      // conj(E + i Op), doubled like the rest
             lds_barrier();
             cf v[16];
 #pragma unroll
@@ -389,41 +388,76 @@ struct RefineArgs {
     double* dbg;                  // optional [ncell][16] fp64 values (tests)
 };
 #define SCR_REF_THREADS 256
+#define SCR_REF_CHUNK (16 * SCR_REF_THREADS)         /* taps staged per step: 16 per thread */
+// LDS staging keeps the global loads coalesced (a thread's own 31 samples are 124 bytes of a line nobody else in the
+// wave touches at that moment): samples and taps of one 4096-tap chunk go to LDS as doubles, element e at
+// e + (e >> 4) -- a thread then reads its 16 taps and 31 samples at a stride of 17 doubles, which is conflict-free.
 template <int DT>
 __global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_kernel(RefineArgs a) {
-    __shared__ double part[SCR_REF_THREADS / 64][16];
+    constexpr int CH = SCR_REF_CHUNK, TH = SCR_REF_THREADS;
+    __shared__ double xs[CH + 16 + (CH + 16) / 16 + 1];
+    __shared__ double cs[CH + CH / 16];
+    __shared__ double part[TH / 64][16];
     __shared__ double P[16];
     typedef typename RawT<DT>::E E;
     if (a.misc->status & 1) return;
     const long long ncell = a.which == 0 ? a.misc->ncellA : a.misc->ncellB;
     const int t = threadIdx.x;
-    const int per = (a.Lc + SCR_REF_THREADS - 1) / SCR_REF_THREADS;
-    const int k_lo = t * per, k_hi = min(a.Lc, k_lo + per);
-    // the grid is fixed (the list length lives on the device): each workgroup takes every gridDim.x-th cell
-    for (long long ci = blockIdx.x; ci < ncell; ci += gridDim.x) {
-        const int64_t c = a.cells[ci];
-        const int64_t m0 = GF3_SCR_CELL * c;
-        const int64_t s0 = m0 - (a.Lc - 1);            // sample index of tap 0 for lag m0
-        double acc[16];
+    const int nch = (a.Lc + CH - 1) / CH;             // chunks per cell
+    // The grid is fixed (the list length lives on the device): each workgroup takes every gridDim.x-th cell.  Its
+    // work is one sequence of (cell, chunk) steps; the raw samples and taps of step i+1 are fetched into registers
+    // while step i is computed out of LDS, so the global-load latency is paid once per workgroup, not per chunk.
+    const long long mine = blockIdx.x < ncell ? (ncell - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const long long nsteps = mine * nch;
+    E xr[17];
+    double cr[16];
+    auto fetch = [&](long long step) {
+        const int64_t c = a.cells[blockIdx.x + (step / nch) * gridDim.x];
+        const int k0 = (int)(step % nch) * CH;
+        const int64_t i0 = GF3_SCR_CELL * c - (a.Lc - 1) + k0;
+        const bool inside = i0 >= 0 && i0 + CH + 15 <= a.n_in;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-        for (int k0 = k_lo; k0 < k_hi; k0 += 16) {
+        for (int q = 0; q < 17; ++q) {
+            const int e = t + TH * q;
+            const int64_t i = i0 + e;
+            xr[q] = (e < CH + 15 && (inside || (i >= 0 && i < a.n_in))) ? ((const E*)a.in)[i] : (E)0;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = k0 + t + TH * q;
+            cr[q] = k < a.Lc ? a.chirp[k] : 0.0;
+        }
+    };
+    if (nsteps > 0) fetch(0);
+    double acc[16];
+    for (long long step = 0; step < nsteps; ++step) {
+        const int ch = (int)(step % nch);
+        const long long ci = blockIdx.x + (step / nch) * gridDim.x;
+        if (ch == 0) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+        }
+        __syncthreads();                               // the previous step has been consumed
+#pragma unroll
+        for (int q = 0; q < 17; ++q) { const int e = t + TH * q; if (e < CH + 15) xs[e + (e >> 4)] = (double)xr[q]; }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int e = t + TH * q; cs[e + (e >> 4)] = cr[q]; }
+        __syncthreads();
+        if (step + 1 < nsteps) fetch(step + 1);
+        {
             double x[31];
-            const int64_t i0 = s0 + k0;
-            if (i0 >= 0 && i0 + 31 <= a.n_in) {
 #pragma unroll
-                for (int i = 0; i < 31; ++i) x[i] = (double)((const E*)a.in)[i0 + i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 31; ++i) x[i] = (i0 + i >= 0 && i0 + i < a.n_in) ? (double)((const E*)a.in)[i0 + i] : 0.0;
-            }
+            for (int i = 0; i < 31; ++i) x[i] = xs[17 * t + i + (i >> 4)];
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                const double ck = (k0 + kk < k_hi) ? a.chirp[k0 + kk] : 0.0;
+                const double ck = cs[17 * t + kk];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[j] = fma(ck, x[kk + j], acc[j]);
             }
         }
+        if (ch != nch - 1) continue;
+        // ---- the cell is complete: reduce the 16 sums over the workgroup and decide
+        const int64_t m0 = GF3_SCR_CELL * a.cells[ci];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             double s = acc[j];
@@ -431,7 +465,6 @@ __global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_kernel(RefineArgs 
             for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
             acc[j] = s;
         }
-        __syncthreads();                               // the previous cell's P[] and part[] have been consumed
         if ((t & 63) == 0) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) part[t >> 6][j] = acc[j];
@@ -439,7 +472,7 @@ __global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_kernel(RefineArgs 
         __syncthreads();
         if (t < 16) {
             double s = 0.0;
-            for (int w = 0; w < SCR_REF_THREADS / 64; ++w) s += part[w][t];
+            for (int w = 0; w < TH / 64; ++w) s += part[w][t];
             P[t] = s;
             if (a.dbg) a.dbg[ci * 16 + t] = s;
         }
@@ -505,4 +538,9 @@ __global__ void scr_expand_kernel(const int64_t* cells, const unsigned* cell_mas
         ++o;
         m &= m - 1;
     }
+}
+
+// a fallen-back call must not walk a candidate list that was never written
+__global__ void scr_guard_kernel(const ScrMisc* misc, int64_t* total) {
+    if (misc->status & 1) total[0] = 0;
 }

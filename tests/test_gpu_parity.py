@@ -767,10 +767,14 @@ def test_stream_screen_error_bound_holds(case):
     P = orc.matched_filter(np.asarray(r, dtype=np.float64), p)
     p32 = p32.cpu().numpy().astype(np.float64); berr = berr.cpu().numpy().astype(np.float64); bmax = bmax.cpu().numpy()
     assert len(p32) == len(P) and hop % 2 == 0
-    err = np.abs(p32 - P)
+    # (the oracle's P is itself an FFT product: allow its own rounding, ~1e-16 |r| |c|, where the bound is tiny)
+    tol = 1e-13 * np.linalg.norm(np.asarray(r, dtype=np.float64)) * np.linalg.norm(orc.chirp_replica(p))
+    err = np.maximum(np.abs(p32 - P) - tol, 0.0)
     per_lag = np.repeat(berr, hop)[: len(P)]
     assert (err <= per_lag).all(), (name, float((err / per_lag).max()))
-    assert (err / np.maximum(per_lag, 1e-300)).max() < 0.125, (name, float((err / per_lag).max()))
+    ratio = float((err / np.maximum(per_lag, 1e-300)).max())
+    print(f"screen bound {name}: realised / bound = {ratio:.4f}")
+    assert ratio < 0.125, (name, ratio)
     nb = len(berr)
     want_max = np.array([p32[b * hop: (b + 1) * hop].max() for b in range(nb)])
     assert np.array_equal(bmax.astype(np.float64), want_max)
