@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
 """Turn the scratch output of tools/profile_round.sh (gpurun_out/round/) into the tracked files under profiles/.
 
-    python tools/collect_profiles.py [--tag r01_final]
+    python tools/collect_profiles.py --tag r02
 
-Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu`),
-profiles/<tag>_bench.json (the bench line of the same run set), profiles/<tag>_config3.json / _config5.log when
-present, and profiles/traffic_current.json (HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes), which
-bench.py reads for `roofline.traffic`.
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu --no-power`),
+profiles/<tag>_bench.json (the bench line of the same run set), profiles/<tag>_pmc.json (HBM bytes per launch from the
+FETCH_SIZE / WRITE_SIZE passes for every kernel of the bench; issue / wait / LDS shares and the clock of the hot
+kernels from the SQ and GRBM passes) and profiles/traffic_current.json, which bench.py reads for `roofline.traffic`.
 
 Counter handling follows MI355X_MICROARCH.md (HBM / rocprofv3 section): separate --pmc passes; values are KB;
-on gfx950 FETCH_SIZE reports about half of coalesced streaming reads, so both counters are calibrated in the same
-run set on rfft_kernel<2048,f32> (tools/config5.py), whose byte counts are known exactly.
+on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so both counters are calibrated in
+the same run on rfft_kernel<2048,f32> over 2^28 samples (bench.py's config-5 leg), whose byte counts are known exactly
+(1 GiB read, 65 536 x 2 049 complex128 bins written).  SQ_* counters are quad-cycles (4 shader clocks).
 """
 import argparse
+import collections
 import csv
 import glob
 import json
@@ -29,69 +31,94 @@ def newest(pattern):
     hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
     if not hits:
         sys.exit(f"missing {pattern} under {SRC}")
-    return max(hits, key=os.path.getmtime)
+    return max(hits, key=os.path.getsize)
 
 
-def counter_mean(sub, counter, kernel_prefix, grid=None):
-    """mean Counter_Value over the dispatches of one kernel (optionally of one grid size)"""
-    vals = []
-    with open(newest(f"{sub}/**/*_counter_collection.csv")) as fh:
-        for row in csv.DictReader(fh):
-            if row["Counter_Name"] != counter or not row["Kernel_Name"].startswith(kernel_prefix):
-                continue
-            if grid is not None and int(row["Grid_Size"]) != grid:
-                continue
-            vals.append(float(row["Counter_Value"]))
-    if not vals:
-        sys.exit(f"no {counter} rows for {kernel_prefix} in {sub}")
-    return sum(vals) / len(vals)
+def counters(sub):
+    """{(kernel, grid): {counter: (mean value, mean duration us, launches)}} over every process of the pass"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(SRC, sub, "**", "*_counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                if "at::native" in k or "rocclr" in k:
+                    continue
+                dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+                acc[(k, int(row["Grid_Size"]))][row["Counter_Name"]].append((float(row["Counter_Value"]), dur))
+    out = {}
+    for key, cs in acc.items():
+        out[key] = {c: (sum(a for a, _ in v) / len(v), sum(b for _, b in v) / len(v), len(v)) for c, v in cs.items()}
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r01_final")
+    ap.add_argument("--tag", default="r02")
     args = ap.parse_args()
     os.makedirs(DST, exist_ok=True)
-
     shutil.copy(newest("trace/**/*_kernel_stats.csv"), os.path.join(DST, f"{args.tag}_kernel_stats.csv"))
     bench = json.loads(open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1])
     json.dump(bench, open(os.path.join(DST, f"{args.tag}_bench.json"), "w"), indent=1)
-    for name in ("config3.json", "config5.log"):
-        p = os.path.join(SRC, name)
-        if os.path.exists(p):
-            shutil.copy(p, os.path.join(DST, f"{args.tag}_{name}"))
 
+    fetch, write, sq, grbm = counters("fetch"), counters("write"), counters("sq"), counters("grbm")
+    big = 16777216                                            # 65 536 workgroups of 256 threads
+    cal_read, cal_write = (1 << 28) * 4, 65536 * 2049 * 16
+    cal_f = fetch[("rfft_kernel<2048, 1>", big)]["FETCH_SIZE"][0] * 1024 / cal_read
+    cal_w = write[("rfft_kernel<2048, 1>", big)]["WRITE_SIZE"][0] * 1024 / cal_write
     F = bench["config"]["frames_per_gpu"]
-    # calibration kernel: tools/config5.py's N=4096 case = rfft_kernel<2048, f32>, 4096 transforms:
-    # reads 2^24 f32 samples, writes 4096 x 2049 complex128 bins
-    cal_read, cal_write = (1 << 24) * 4, 4096 * 2049 * 16
-    cal_f = counter_mean("cal_fetch", "FETCH_SIZE", "void rfft_kernel<2048, 1>") * 1024 / cal_read
-    cal_w = counter_mean("cal_write", "WRITE_SIZE", "void rfft_kernel<2048, 1>") * 1024 / cal_write
-    raw, corr = {}, {}
-    algo = {"demod_kernel": bench["roofline"]["algorithmic_bytes_per_launch"],
-            "corr_kernel": bench["roofline_sync"]["algorithmic_bytes_per_launch"]}
-    for k in ("demod_kernel", "corr_kernel"):
-        f = counter_mean("fetch", "FETCH_SIZE", f"void {k}<")
-        w = counter_mean("write", "WRITE_SIZE", f"void {k}<")
-        raw[k] = {"FETCH_SIZE": f, "WRITE_SIZE": w}
-        corr[k] = {"read": f * 1024 / cal_f, "write": w * 1024 / cal_w, "algorithmic": algo[k]}
-    out = {
-        "_comment": "HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; "
-                    "python3 bench.py --steps 2 --warmup 1 --no-cpu). Counters are in KB. gfx950 correction "
-                    "(MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of coalesced streaming reads; "
-                    "calibrated in the same run set on rfft_kernel<2048,f32> (tools/config5.py), whose byte counts "
-                    "are known. Produced by tools/collect_profiles.py.",
-        "calibration": {"fetch_reported_over_actual": cal_f, "write_reported_over_actual": cal_w},
-        "raw_KB": raw,
-        f"corrected_bytes_per_launch_F{F}": corr,
-        "demod_kernel_bytes_per_launch_at_F": {str(F): corr["demod_kernel"]["read"] + corr["demod_kernel"]["write"]},
-    }
-    json.dump(out, open(os.path.join(DST, "traffic_current.json"), "w"), indent=1)
-    d = corr["demod_kernel"]
-    print(f"demod: read {d['read'] / 1e9:.3f} GB + write {d['write'] / 1e9:.3f} GB vs algorithmic {d['algorithmic'] / 1e9:.3f} GB")
-    c = corr["corr_kernel"]
-    print(f"sync : read {c['read'] / 1e9:.3f} GB + write {c['write'] / 1e9:.3f} GB vs algorithmic {c['algorithmic'] / 1e9:.3f} GB")
-    print(f"calibration: fetch x{cal_f:.4f}, write x{cal_w:.4f}")
+    algo = {"demod_kernel<2048, 1, false, 2>": bench["roofline"]["algorithmic_bytes_per_launch"],
+            "corr_kernel<1024, 1>": bench["roofline_sync"]["algorithmic_bytes_per_launch"]}
+    for k, leg in (("demod_kernel<2048, 1, false, 1>", "roofline_demod_16qam"), ("soft_demap_sep_kernel<6>", "roofline_soft_demap")):
+        if leg in bench:
+            algo[k] = bench[leg]["algorithmic_bytes_per_launch"]
+    for N, leg in bench.get("roofline_rfft", {}).items():
+        algo[f"rfft_kernel<{int(N[1:]) // 2}, 1>"] = leg["algorithmic_bytes_per_launch"]
+    if "roofline_stream_sync" in bench:
+        algo["scr_ols_kernel<1>"] = bench["roofline_stream_sync"]["algorithmic_bytes_per_call"]
+    traffic = {}
+    for (k, grid), cs in sorted(fetch.items()):
+        if (k, grid) not in write or cs["FETCH_SIZE"][1] < 100.0:       # launches under 0.1 ms: set-up transforms, tiny lists
+            continue
+        f_kb, w_kb = cs["FETCH_SIZE"][0], write[(k, grid)]["WRITE_SIZE"][0]
+        ent = {"grid_threads": grid, "launches_profiled": cs["FETCH_SIZE"][2], "avg_us_under_pmc": round(cs["FETCH_SIZE"][1], 1),
+               "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
+               "read_bytes_corrected": f_kb * 1024 / cal_f, "write_bytes_corrected": w_kb * 1024 / cal_w}
+        ent["hbm_bytes"] = ent["read_bytes_corrected"] + ent["write_bytes_corrected"]
+        if k in algo and (grid == big or k.startswith(("scr_", "soft_")) or (k.startswith("corr_") and grid == big // 2)):
+            ent["algorithmic_bytes"] = algo[k]
+            ent["traffic_over_algorithmic"] = ent["hbm_bytes"] / algo[k]
+        traffic[f"{k} grid={grid}"] = ent
+    shares = {}
+    for (k, grid), cs in sorted(sq.items()):
+        if "SQ_WAVE_CYCLES" not in cs or cs["SQ_WAVE_CYCLES"][1] < 100.0:
+            continue
+        wc = cs["SQ_WAVE_CYCLES"][0]
+        ent = {"grid_threads": grid, "avg_us_under_pmc": round(cs["SQ_WAVE_CYCLES"][1], 1),
+               "valu_wave_instructions": cs["SQ_INSTS_VALU"][0], "lds_wave_instructions": cs["SQ_INSTS_LDS"][0],
+               "share_of_wave_cycles": {"valu_issue": cs["SQ_ACTIVE_INST_VALU"][0] / wc, "lds_issue": cs["SQ_ACTIVE_INST_LDS"][0] / wc,
+                                        "waiting_waitcnt_or_barrier": cs["SQ_WAIT_ANY"][0] / wc, "issue_stalled": cs["SQ_WAIT_INST_ANY"][0] / wc}}
+        g = grbm.get((k, grid))
+        if g and "GRBM_GUI_ACTIVE" in g:
+            ent["clock_GHz_under_pmc"] = g["GRBM_GUI_ACTIVE"][0] / 8 / (g["GRBM_GUI_ACTIVE"][1] * 1e-6) / 1e9
+            ent["lds_bank_conflict_share_of_lds_cycles"] = g["SQ_LDS_BANK_CONFLICT"][0] / max(1.0, g["SQ_LDS_IDX_ACTIVE"][0])
+        shares[f"{k} grid={grid}"] = ent
+    out = {"_comment": "rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu --no-power` (FETCH_SIZE, WRITE_SIZE: full bench; "
+                       "SQ and GRBM: hot-path legs only). KB counters; FETCH_SIZE calibrated on rfft_kernel<2048,f32> over 2^28 samples in the "
+                       "same run (MI355X_MICROARCH.md: gfx950 reports half of wide streaming reads); narrower access patterns "
+                       "(scr_ols_kernel's 8-byte sample pairs) are corrected by the same factor and are upper bounds. Produced by tools/collect_profiles.py.",
+           "calibration": {"fetch_reported_over_actual": cal_f, "write_reported_over_actual": cal_w},
+           "hbm_traffic_per_launch": traffic, "sq_shares": shares}
+    json.dump(out, open(os.path.join(DST, f"{args.tag}_pmc.json"), "w"), indent=1)
+    d = traffic[f"demod_kernel<2048, 1, false, 2> grid={big}"]
+    json.dump({"_comment": f"see {args.tag}_pmc.json", "calibration": out["calibration"],
+               "demod_kernel_bytes_per_launch_at_F": {str(F): d["hbm_bytes"]}},
+              open(os.path.join(DST, "traffic_current.json"), "w"), indent=1)
+    for k, e in traffic.items():
+        if "traffic_over_algorithmic" in e:
+            print(f"{k:55s} HBM {e['hbm_bytes'] / 1e9:7.3f} GB = {e['traffic_over_algorithmic']:.3f} x algorithmic")
+    for k, e in shares.items():
+        s = e["share_of_wave_cycles"]
+        print(f"{k:55s} VALU {s['valu_issue']:.2f} LDS {s['lds_issue']:.2f} wait {s['waiting_waitcnt_or_barrier']:.2f} stall {s['issue_stalled']:.2f} clk {e.get('clock_GHz_under_pmc', 0):.2f} GHz")
 
 
 if __name__ == "__main__":
