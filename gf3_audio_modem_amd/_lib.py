@@ -46,6 +46,9 @@ _SIGS = {
     "gf3_sync_stream_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "gf3_sync_stream_info": (C.c_int, [C.c_void_p, c_i64_p]),
     "gf3_debug_stream_screen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "gf3_known_h_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "gf3_equalise_known_h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gf3_tx_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                 C.c_int32, C.c_void_p]),
     "gf3_schmidl_cox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),

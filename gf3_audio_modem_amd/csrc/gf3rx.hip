@@ -2153,6 +2153,58 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     return GF3_OK;
 }
 
+static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, uint8_t* idx, float* llr, double nv, void* stream);
+__global__ void zf_bins_kernel(const int* pos, int K, int* bins) {      // bins[pos[k]] = k + 1 for every data carrier
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K && pos[k] >= 0) bins[pos[k]] = k + 1;
+}
+// ============================================================================
+// known-channel zero forcing (the reference's older flow, `Weekend Challenge.ipynb` cells 9-15: H = fft(h, N),
+// symbols = FFT(rx) / H on bins 1..N/2-1).  Not on receive()'s path and without a surviving reference function:
+// parity is pinned by the formula only (oracle.zf_known_h).
+// ============================================================================
+struct ZfArgs { const cplx* X; const cplx* H; const int* bins; int64_t n_sym; int C, NC; cplx* eq; };
+__global__ void zf_kernel(ZfArgs a) {
+    const int64_t total = a.n_sym * a.C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / a.C;
+        const int b = a.bins[i - s * a.C];
+        a.eq[i] = cdiv_np(a.X[s * (a.NC + 1) + b], a.H[b]);              // complex128 division as NumPy performs it
+    }
+}
+extern "C" int64_t gf3_known_h_workspace_bytes(const gf3_ctx* c, int64_t n_sym) {
+    if (!c || n_sym < 0) return 0;
+    return (int64_t)((size_t)(n_sym + 1) * (c->NC + 1) * sizeof(cplx) + (size_t)2 * c->NC * sizeof(double) + 16 + (size_t)c->cfg.C * 4 + 256);
+}
+extern "C" int gf3_equalise_known_h(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_offsets, int64_t n_sym,
+                                    const double* d_h, int32_t n_taps, void* d_eq, uint8_t* d_bits, uint8_t* d_idx,
+                                    void* d_work, void* stream) {
+    DeviceGuard dg(c);
+    if (c && n_sym == 0) return GF3_OK;
+    if (!c || !d_in || !d_offsets || !d_h || !d_eq || !d_bits || !d_work || n_sym < 0 || n_taps < 1 || n_taps > 2 * c->NC)
+        return fail(c, GF3_EINVAL, "gf3_equalise_known_h: bad argument (1 <= n_taps <= N)");
+    hipStream_t st = (hipStream_t)stream;
+    const int NC = c->NC, N = 2 * NC;
+    char* base = (char*)d_work;
+    cplx* X = (cplx*)base;                                               // [n_sym][NC+1]
+    cplx* H = X + (size_t)n_sym * (NC + 1);                              // [NC+1]
+    double* hpad = (double*)(H + (NC + 1));                              // [N] taps, zero padded (np.fft.fft(h, N))
+    int64_t* zero = (int64_t*)(hpad + N);                                // offset 0 of the padded taps
+    int* bins = (int*)(zero + 2);
+    HIPCHK(c, hipMemsetAsync(hpad, 0, (size_t)N * sizeof(double) + 16, st));
+    HIPCHK(c, hipMemcpyAsync(hpad, d_h, (size_t)n_taps * sizeof(double), hipMemcpyDeviceToDevice, st));
+    // data-carrier bins in output order (the context keeps the carrier -> position map; invert it on the device)
+    hipLaunchKernelGGL(zf_bins_kernel, dim3((c->K + 255) / 256), dim3(256), 0, st, (const int*)c->d_pos, c->K, bins);
+    HIPCHK(c, run_rfft_nc(NC, FftTables{c->d_tw, c->d_twn}, hpad, N, DT_F64, zero, 1, H, st));
+    HIPCHK(c, run_rfft(c, d_in, n_in, c->cfg.in_dtype, d_offsets, n_sym, X, st));
+    ZfArgs a{X, H, bins, n_sym, c->cfg.C, NC, (cplx*)d_eq};
+    int64_t grid = (n_sym * c->cfg.C + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(zf_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
+    HIPCHK(c, hipGetLastError());
+    return run_demap(c, d_eq, n_sym * c->cfg.C, d_bits, d_idx, nullptr, 1.0, stream);
+}
+
 static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, uint8_t* idx, float* llr, double nv, void* stream) {
     DemapArgs a{(const cplx*)d_sym, n, c->cfg.M, c->cfg.mu, c->d_cre, c->d_cim, c->d_clab, bits, llr, nv > 0 ? 1.0 / nv : 0.0, idx, c->sep};
     int64_t grid = (n + 255) / 256;

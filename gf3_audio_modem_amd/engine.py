@@ -321,6 +321,21 @@ class Engine:
         self._check(self.lib.gf3_schmidl_cox(self._h, _ptr(x), x.numel(), S, _ptr(out), self._stream()))
         return int(out.item())
 
+    def equalise_known_h(self, x, sym_offsets, h):
+        """Known-channel zero forcing (Weekend Challenge.ipynb cells 9-17): FFT(rx) / fft(h, N) on the data carriers,
+        then demap.  Returns (eq [n_sym, C] complex128, bits [n_sym, C, mu] uint8, idx [n_sym, C] uint8)."""
+        x = self._samples(x)
+        off = torch.as_tensor(sym_offsets, dtype=torch.int64).to(self.device).contiguous()
+        taps = torch.as_tensor(np.asarray(h, dtype=np.float64)).to(self.device).contiguous()
+        n = off.numel()
+        eq = self._new((n, self.cfg.C), torch.complex128)
+        bits = self._new((n, self.cfg.C, self.cfg.mu), torch.uint8)
+        idx = self._new((n, self.cfg.C), torch.uint8)
+        work = self._new((int(self.lib.gf3_known_h_workspace_bytes(self._h, n)),), torch.uint8)
+        self._check(self.lib.gf3_equalise_known_h(self._h, _ptr(x), x.numel(), _ptr(off), n, _ptr(taps), taps.numel(),
+                                                  _ptr(eq), _ptr(bits), _ptr(idx), _ptr(work), self._stream()))
+        return eq, bits, idx
+
     def demap_hard(self, sym):
         sym = torch.as_tensor(sym, dtype=torch.complex128).to(self.device).contiguous()
         n = sym.numel()

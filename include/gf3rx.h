@@ -209,6 +209,21 @@ int gf3_tx_frames(gf3_ctx *ctx, const uint8_t *d_bits_packed, const void *d_fill
                   const int64_t *d_gaps, int64_t F, void *d_out, int64_t stride,
                   int32_t out_dtype, void *stream);
 
+/*
+ * Known-channel zero forcing, the reference's older receive flow (`Weekend Challenge.ipynb` cells 9-19:
+ * H = np.fft.fft(h, N); symbols = FFT(rx_no_cp) / H; demap of the data carriers): an optional extra mode with
+ * sample-exact timing supplied by the caller, not part of receive() (OFDM.py:581-657 estimates the channel from
+ * pilots instead, gf3_demod_frames).  The function it used (`equalise(OFDM_demod, H)`) no longer exists in OFDM.py, so
+ * parity is pinned by the formula only.
+ *   d_offsets [n_sym] int64: first of the N samples of each symbol (past its prefix);  d_h [n_taps] float64 channel taps
+ *   d_eq [n_sym, C] complex128 equalised data-carrier symbols;  d_bits [n_sym*C*mu] one byte per bit;  d_idx optional
+ *   d_work: gf3_known_h_workspace_bytes(ctx, n_sym) bytes
+ */
+int64_t gf3_known_h_workspace_bytes(const gf3_ctx *ctx, int64_t n_sym);
+int gf3_equalise_known_h(gf3_ctx *ctx, const void *d_in, int64_t n_in, const int64_t *d_offsets, int64_t n_sym,
+                         const double *d_h, int32_t n_taps, void *d_eq_c128, uint8_t *d_bits_u8,
+                         uint8_t *d_idx_u8_or_null, void *d_work, void *stream);
+
 /* max-log soft demapping (not in the reference; LLR > 0 <=> bit 0). [n*mu] f32 */
 int gf3_soft_demap(gf3_ctx *ctx, const void *d_sym_c128, int64_t n,
                    double noise_var, float *d_llr_f32, void *stream);

@@ -366,6 +366,19 @@ def soft_demap_maxlog(sym, noise_var, p: RxParams):
     return out
 
 
+def zf_known_h(r, sym_offsets, h, p: RxParams):
+    """Known-channel zero forcing of the reference's older flow (`Weekend Challenge.ipynb` cells 9-17):
+    H = np.fft.fft(h, N); symbols = np.fft.fft(rx_no_cp) / H; data carriers; demap.  PARITY UNPINNED: the
+    `equalise(OFDM_demod, H)` it called no longer exists in OFDM.py and its input file is missing, so only the
+    formula is restated.  -> (eq [n_sym, C], bits [n_sym, C, mu])"""
+    r = np.asarray(r, dtype=np.float64)
+    sym = np.stack([r[o: o + p.N] for o in sym_offsets])
+    H = np.fft.fft(np.asarray(h, dtype=np.float64), p.N)
+    eq = (np.fft.fft(sym) / H)[:, p.data_carriers]
+    bits, _ = demap_hard(eq, p)
+    return eq, bits
+
+
 # --------------------------------------------------------------------------
 # whole receive (OFDM.py:581-657) on explicit frame starts or via sync
 # --------------------------------------------------------------------------

@@ -830,3 +830,34 @@ def test_stream_sync_falls_back_when_the_screen_is_not_selective():
     got2 = eng.sync_stream(torch.from_numpy(r2).cuda(), cap=4096).cpu().numpy()
     assert eng.sync_stream_info()["path"] == 0
     assert np.array_equal(got2, np.flatnonzero(orc.chirp_method(r2, p)))
+
+
+@pytest.mark.parametrize("mu,dt", [(2, torch.float64), (4, torch.float32), (6, torch.float64)])
+def test_known_channel_zero_forcing(mu, dt):
+    """gf3_equalise_known_h (the reference's older known-H flow, Weekend Challenge.ipynb cells 9-17) against the
+    oracle's restatement of the formula: FFT(rx)/fft(h, N), data carriers, demap -- stream through the measured
+    30-tap channel with sample-exact symbol offsets; noiseless, so the payload comes back too.  Parity unpinned
+    (no reference function survives); the comparison is engine vs oracle on the same samples."""
+    from scipy.signal import lfilter
+    g = load("g3_n4096_16qam_gr5")
+    pts, bt = orc.qpsk_table() if mu == 2 else orc.square_qam_table(mu)
+    K = 2047
+    known = np.tile(g["known_bits"].astype(np.uint8), -(-K * mu // len(g["known_bits"])))
+    p = orc.RxParams(N=4096, CP=512, P=1, D=5, lo=100, hi=1500, const_points=pts, const_bits=bt.astype(np.int64), known_bits=known)
+    rs = np.random.RandomState(mu)
+    F = 2
+    payload = rs.randint(0, 2, F * p.D * p.C * p.mu)
+    fill = rs.choice(orc.qpsk_table()[0], size=K - p.C)
+    r = lfilter(g["channel"], 1.0, orc.tx_stream(payload, fill, p, lead=37, tail=50))
+    if dt == torch.float32:
+        r = r.astype(np.float32)
+    # data symbols of packet f start (past their prefix) at lead + f frame_len + Lc + (P + l) S + CP
+    offs = np.array([37 + f * p.frame_len + p.Lc + (p.P + l) * p.S + p.CP for f in range(F) for l in range(p.D)])
+    h = 2.0 * g["channel"]                                  # the transmitter's x2 symbol gain (OFDM.py:256) is part of "the channel"
+    ref_eq, ref_bits = orc.zf_known_h(np.asarray(r, dtype=np.float64), offs, h, p)
+    eng = engine_for(p, in_dtype=dt)
+    eq, bits, idx = eng.equalise_known_h(torch.from_numpy(r).cuda(), offs, h)
+    assert np.abs(eq.cpu().numpy() - ref_eq).max() <= 1e-9 * max(1.0, np.abs(ref_eq).max())
+    assert np.array_equal(bits.cpu().numpy(), ref_bits)
+    if dt == torch.float64:
+        assert np.array_equal(bits.cpu().numpy().reshape(-1), payload)       # noiseless + known channel => BER 0
