@@ -461,18 +461,6 @@ def main():
     chunks, Fc = run.chunks, run.Fc
     step = run.step
 
-    # N>1: the same batch once more with the literal single all-gather of the north_star (one collective per step,
-    # issued after the kernels, nothing overlapped), reported beside the chunked result
-    single = None
-    if multi and run.chunks != 1:
-        del run.gathered, run.og
-        run1 = Run(1)
-        dt1, _ = run1.timed(min(args.warmup, 2), args.steps)
-        be1, so1, go1 = run1.verify()
-        single = {"chunks": 1, "ms_per_step": dt1 / args.steps * 1e3, "value": world * n_samples * args.steps / dt1,
-                  "unit": "samples/s", "bit_errors": be1, "sync_exact": so1, "gather_exact": go1}
-        del run1
-
     # sustained package power: the same step repeated for ~2 s after the timed region (the hwmon sensor averages
     # over a window far longer than a 20-step run), median of the second half of the samples
     power_w = None
@@ -489,6 +477,18 @@ def main():
             if power.samples:
                 power_w = float(np.median(power.samples[len(power.samples) // 2:]))
         gd.barrier()
+
+    # N>1: the same batch once more with the literal single all-gather of the north_star (one collective per step,
+    # issued after the kernels, nothing overlapped), reported beside the chunked result
+    single = None
+    if multi and run.chunks != 1:
+        del run.gathered, run.og
+        run1 = Run(1)
+        dt1, _ = run1.timed(min(args.warmup, 2), args.steps)
+        be1, so1, go1 = run1.verify()
+        single = {"chunks": 1, "ms_per_step": dt1 / args.steps * 1e3, "value": world * n_samples * args.steps / dt1,
+                  "unit": "samples/s", "bit_errors": be1, "sync_exact": so1, "gather_exact": go1}
+        del run1
 
     t_sync = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])) * 1e-3
     t_demod = float(np.mean([(e[3] if multi else e[1]).elapsed_time(e[2]) for e in evs])) * 1e-3
