@@ -77,3 +77,41 @@ def test_gpu_tx_sync_demod_round_trip(N, F, storage, cp_frac, P, D, mu, lo_frac,
         ref = orc.demod_frames(x, starts.cpu().numpy(), p)
         assert np.array_equal(bits, ref["bits"].reshape(-1))
         np.testing.assert_allclose(o["slope"].cpu().numpy(), ref["slope"], rtol=0, atol=1e-10)
+
+
+@pytest.mark.gpu
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(N=st.sampled_from([1024, 2048, 4096, 8192]), F=st.integers(1, 3), cp_frac=st.sampled_from([1 / 32, 1 / 8, 1 / 4, 1 / 2]),
+       storage=st.sampled_from(["float64", "float32", "int16", "uint8"]), snr_db=st.sampled_from([60.0, 20.0, 6.0]),
+       seed=st.integers(0, 2 ** 31 - 1))
+def test_gpu_stream_sync_matches_oracle(N, F, cp_frac, storage, snr_db, seed):
+    """chirp_method on whole streams over random geometries (chirp lengths 5 280 ... 61 440: 2 to 15 screening
+    partitions), sample storage and noise levels: the engine's peaks -- fp32 screen + fp64 decisions, and the all-fp64
+    path -- equal the oracle's on the same (rounded) samples."""
+    import torch
+    from gf3_audio_modem_amd import Engine, RxConfig
+    p = _params(N, cp_frac, 1, 2, 2, 0.0, 0.0)
+    dt = getattr(torch, storage)
+    rs = np.random.RandomState(seed)
+    payload = rs.randint(0, 2, F * p.D * p.C * p.mu)
+    fill = rs.choice(np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2), size=p.K - p.C)
+    r = orc.tx_stream(payload, fill, p, gaps=rs.randint(0, 400, F), lead=int(rs.randint(0, 3000)), tail=int(rs.randint(2, 500)))
+    r = r + rs.randn(len(r)) * np.sqrt(np.mean(r * r)) * 10 ** (-snr_db / 20)
+    if storage == "int16":
+        rq = np.round(r / np.abs(r).max() * 20000).astype(np.int16)
+    elif storage == "uint8":
+        rq = np.round(r / np.abs(r).max() * 100 + 128).astype(np.uint8)          # DC offset 128, as an 8-bit wav has
+    else:
+        rq = r.astype(storage)
+    want = np.flatnonzero(orc.chirp_method(rq.astype(np.float64), p))
+    cfg = RxConfig(N=p.N, CP=p.CP, P=p.P, D=p.D, data_bins=p.data_carriers, const_points=p.const_points, const_bits=p.const_bits,
+                   known_bits=p.known_bits, in_dtype=dt, fit_lo=p.fit_lo, fit_hi=p.fit_hi)
+    eng = Engine(cfg)
+    x = torch.from_numpy(rq).cuda()
+    got = eng.sync_stream(x).cpu().numpy()
+    info = eng.sync_stream_info()
+    assert np.array_equal(got, want), (info, got, want)
+    assert info["path"] in (0, 1)
+    eng.sync_stream_mode(1)
+    assert np.array_equal(eng.sync_stream(x).cpu().numpy(), want)
+    eng.close()
