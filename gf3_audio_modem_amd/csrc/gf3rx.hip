@@ -783,7 +783,7 @@ __global__ __launch_bounds__(NC / 8, 2) void spec_kernel(OlsArgs a) {
     }
 }
 
-#define OLS_B 4      /* output blocks per workgroup */
+#define OLS_B 3      /* output blocks per workgroup */
 template <int NC>
 __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
     // OLS_B adjacent output blocks per workgroup: blocks b .. b+B-1 need windows b .. b+Q+B-2 and share most of

@@ -70,8 +70,12 @@ def measure(eng, cfg, r, payload, reps=3, worst=3):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=4096)
+    ap.add_argument("--fp64-sync", action="store_true", help="gf3_sync_stream_mode(1): the all-fp64 overlap-save instead of screen + fp64 decisions")
     args = ap.parse_args()
     eng, cfg, channel = make_engine()
+    if args.fp64_sync:
+        eng.sync_stream_mode(1)
     r, payload = make_stream(eng, channel, args.frames)
     res, _, _ = measure(eng, cfg, r, payload)
+    res["sync_path"] = eng.sync_stream_info()
     print(json.dumps(res))
