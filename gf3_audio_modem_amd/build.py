@@ -18,7 +18,10 @@ DEPS = SRC + [os.path.join(HERE, "csrc", "gf3rx_device.h"), os.path.join(HERE, "
               os.path.join(ROOT, "include", "gf3rx.h")]
 LIB = os.path.join(HERE, "lib", "libgf3rx.so")
 STAMP = LIB + ".srchash"
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"]
+# -fno-slp-vectorize: LLVM otherwise pairs the screening kernel's fp32 complex arithmetic into v_pk_* instructions,
+# which issue at half rate on gfx950 and need register shuffles (scr_ols_kernel 3.0 -> 2.6 ms without them; the fp64
+# kernels, which have no packed form, are unchanged)
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize"]
 
 
 def lib_path():

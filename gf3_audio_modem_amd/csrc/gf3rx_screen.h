@@ -220,10 +220,10 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
         for (int g = 0; g < B; ++g) {
             const int h = w - g;
             if (h >= 0 && h < a.Q) {
-                const float4* Hp = a.Hs + ((int64_t)h * 8) * T + t;
+                const float4* Hp = a.Hs + ((int64_t)h * 8) * T;            // wave-uniform base + 32-bit lane offset
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
-                    const float4 hh = Hp[r * T];
+                    const float4 hh = Hp[(unsigned)(r * T + t)];
                     acc[g][2 * r] = cf_fma_conj(v[2 * r], cfmk(hh.x, hh.y), acc[g][2 * r]);
                     acc[g][2 * r + 1] = cf_fma_conj(v[2 * r + 1], cfmk(hh.z, hh.w), acc[g][2 * r + 1]);
                 }
