@@ -71,8 +71,12 @@ struct DemodArgs {
 #ifdef GF3_STAMPS
 #define GF3_STAMP(i) do { if (a.stamps && threadIdx.x == 0) { unsigned long long t_; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); a.stamps[blockIdx.x * 8 + (i)] = t_; } } while (0)
+// slots 6 / 7: s_memrealtime (100 MHz) next to the first / last s_memtime stamp -> shader clock = d(memtime) / d(memrealtime) x 100 MHz
+#define GF3_STAMP_RT(i) do { if (a.stamps && threadIdx.x == 0) { unsigned long long t_; \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); a.stamps[blockIdx.x * 8 + (i)] = t_; } } while (0)
 #else
 #define GF3_STAMP(i) do { } while (0)
+#define GF3_STAMP_RT(i) do { } while (0)
 #endif
 
 // occupancy targets: min waves per SIMD handed to __launch_bounds__ (blocks of NC/8 threads).
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         for (int s2 = 0; s2 < 8; ++s2) v[s2] = sp[bin_of(s2) - 1];
     };
     GF3_STAMP(0);
+    GF3_STAMP_RT(6);
     if constexpr (!SPECTRA) fetch(0);
 
     // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451).
@@ -574,6 +579,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     lds_barrier();
     pack_words(D - 1, ((D * Bs) & 31) != 0);
     GF3_STAMP(5);
+    GF3_STAMP_RT(7);
 }
 
 // ============================================================================

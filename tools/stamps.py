@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, ctypes as C
 from gf3_audio_modem_amd import Engine, RxConfig, qpsk_table
 
-N, CP, P, D, F = 4096, 512, 2, 8, 16384
+N, CP, P, D, F = 4096, 512, 2, 8, int(os.environ.get("GF3_STAMPS_FRAMES", "16384"))
 K = N // 2 - 1
 pts, bt = qpsk_table()
 known = np.unpackbits(np.load(os.path.join(os.path.dirname(__file__), "..", "gf3_audio_modem_amd", "data", "known_bits.npz"))["packed"])
@@ -22,9 +22,18 @@ big = eng.tx_frames(payload, filler, stride=stride, gaps=gaps, out_dtype=torch.f
 starts = eng.sync_frames(big, F, stride, -8, 312)
 st = torch.zeros((F, 8), dtype=torch.int64, device="cuda")
 eng.lib.gf3_debug_set_stamps(eng._h, C.c_void_p(st.data_ptr()))
-for _ in range(3):
-    eng.demod_frames(big, starts)
-torch.cuda.synchronize()
+import time, importlib.util
+_spec = importlib.util.spec_from_file_location("gf3_bench", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+_bench = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_bench)
+_ps = _bench.PowerSampler(0); _ps.__enter__()
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < float(os.environ.get("GF3_STAMPS_SECONDS", "2.5")):     # sustained load: the clock settles after ~2 s
+    for _ in range(20):
+        eng.demod_frames(big, starts)
+    torch.cuda.synchronize()
+_ps.__exit__()
+if _ps.samples:
+    print(f"package power while looping: median of the second half {np.median(_ps.samples[len(_ps.samples) // 2:]):.0f} W over {len(_ps.samples)} samples")
 s = st.cpu().numpy().astype(np.float64)
 d = np.diff(s[:, :6], axis=1)
 names = ["start + start-pilot sum", "start + end pilot transforms", "finalize (H, angles, slope)", "data symbols", "last pack + exit"]
