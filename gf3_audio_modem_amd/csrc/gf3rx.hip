@@ -1265,7 +1265,7 @@ struct gf3_ctx {
     // single-precision screening plan of the stream-mode sync (gf3rx_screen.h); ok = false: always the fp64 path
     struct { bool ok = false; int Q = 0, H = 0; cf *d_tw = nullptr, *d_twn = nullptr; float4* d_Hs = nullptr;
              float *d_H0N = nullptr, *d_Hinf = nullptr; } scr;
-    int stream_mode = 0;                // 0: screen first, fp64 when asked for P or when the screen is not selective; 1: fp64 only
+    int stream_mode = 0;                // 0: by stream length (screen from GF3_SCR_MIN_SAMPLES on); 1: fp64 only; 2: screen whenever a plan exists
     int64_t last_info[4] = {0, 0, 0, 0};   // last gf3_sync_stream: path taken (0 screened, 1 fp64 after fallback, 2 fp64), cells A, cells B, candidates
     std::vector<double> chirp;
     std::vector<cplx> known_pts;
@@ -2058,8 +2058,11 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
     return GF3_OK;
 }
 
+// Below this many samples the dozen small launches of the screened path cost more than the fp64 transforms they save
+// (3 M-sample recording: 0.24 ms screened, 0.15 ms all-fp64; 321 M samples: 3.8 vs 7.2 ms; the lines cross near 7 M).
+#define GF3_SCR_MIN_SAMPLES ((int64_t)1 << 23)
 extern "C" int gf3_sync_stream_mode(gf3_ctx* c, int32_t mode) {
-    if (!c || mode < 0 || mode > 1) return fail(c, GF3_EINVAL, "gf3_sync_stream_mode: mode must be 0 (screened) or 1 (fp64 only)");
+    if (!c || mode < 0 || mode > 2) return fail(c, GF3_EINVAL, "gf3_sync_stream_mode: mode must be 0 (by length), 1 (fp64 only) or 2 (always screen)");
     c->stream_mode = mode;
     return GF3_OK;
 }
@@ -2104,7 +2107,7 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     int64_t* np = (int64_t*)(base + w.o_misc + 16);        // [count, status]
     const CorrPlan& pl = c->stream_plan;
     c->last_info[0] = 2; c->last_info[1] = c->last_info[2] = c->last_info[3] = 0;
-    if (!d_corr && c->stream_mode == 0 && c->scr.ok && w.s_nblk > 0) {
+    if (!d_corr && c->scr.ok && w.s_nblk > 0 && (c->stream_mode == 2 || (c->stream_mode == 0 && n >= GF3_SCR_MIN_SAMPLES))) {
         int rc = sync_stream_screened(c, d_r, n, w, base, d_peaks, cap, nullptr, st);
         if (rc != GF3_OK) return rc;
         int64_t h[2] = {0, 0};

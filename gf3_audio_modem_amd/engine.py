@@ -268,8 +268,9 @@ class Engine:
         return (peaks, corr) if want_corr else peaks
 
     def sync_stream_mode(self, mode):
-        """0 (default): fp32 screening + fp64 decisions, all-fp64 when the screen is not selective or P is asked for;
-        1: always the all-fp64 overlap-save path (gf3_sync_stream_mode)."""
+        """gf3_sync_stream_mode: 0 (default) fp32 screening + fp64 decisions from 2^23 samples on, all-fp64 below;
+        1 always the all-fp64 overlap-save path; 2 screened at any length.  (A screen that is not selective, and any
+        call that asks for P, takes the all-fp64 path regardless.)"""
         self._check(self.lib.gf3_sync_stream_mode(self._h, int(mode)))
 
     def sync_stream_info(self):

@@ -164,11 +164,14 @@ int gf3_sync_stream(gf3_ctx *ctx, const void *d_r, int64_t n,
                     void *d_work, double *d_corr_or_null, void *stream);
 
 /*
- * How gf3_sync_stream evaluates the matched filter.  mode 0 (default): every lag is first evaluated in fp32 with a
- * proven error bound; only the lags that the bound cannot exclude (a few around every chirp) are re-evaluated as fp64
- * dot products, and the reference's rule (global maximum, threshold, extremum test) is applied to those fp64 values --
- * no decision rests on an fp32 number; streams on which the screen is not selective, and calls that ask for d_corr,
- * take the all-fp64 overlap-save path.  mode 1: always the all-fp64 path.
+ * How gf3_sync_stream evaluates the matched filter.  Screened: every lag is first evaluated in fp32 with a proven
+ * error bound; only the lags that the bound cannot exclude (a few around every chirp) are re-evaluated as fp64 dot
+ * products, and the reference's rule (global maximum, threshold, extremum test) is applied to those fp64 values -- no
+ * decision rests on an fp32 number; streams on which the screen is not selective take the all-fp64 overlap-save.
+ * mode 0 (default): screened for streams of 2^23 samples or more (below that the all-fp64 path is the faster one);
+ * mode 1: always all-fp64; mode 2: screened at any length.  Calls that ask for d_corr are always all-fp64.
+ * The mode and the info block below are plain fields of the context: set / read them from the thread that calls
+ * gf3_sync_stream on that context.
  */
 int gf3_sync_stream_mode(gf3_ctx *ctx, int32_t mode);
 /* h_out4 (host): of the last gf3_sync_stream call: path (0 screened, 1 fp64 after a non-selective screen, 2 fp64),

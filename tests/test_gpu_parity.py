@@ -794,6 +794,7 @@ def test_stream_sync_screened_equals_fp64_path(name):
         want = np.flatnonzero(orc.chirp_method(rq.astype(np.float64), p))
         if dt == torch.float64:
             assert np.array_equal(want, g["peaks"])
+        eng.sync_stream_mode(2)                                             # (mode 0 screens from 2^23 samples on only)
         got = eng.sync_stream(x).cpu().numpy()
         info = eng.sync_stream_info()
         assert np.array_equal(got, want)
@@ -802,6 +803,8 @@ def test_stream_sync_screened_equals_fp64_path(name):
         assert np.array_equal(eng.sync_stream(x).cpu().numpy(), want)
         assert eng.sync_stream_info()["path"] == 2
         eng.sync_stream_mode(0)
+        assert np.array_equal(eng.sync_stream(x).cpu().numpy(), want) and eng.sync_stream_info()["path"] == 2   # short stream
+        eng.sync_stream_mode(2)
         peaks, corr = eng.sync_stream(x, want_corr=True)                    # asking for P takes the fp64 path
         assert eng.sync_stream_info()["path"] == 2 and np.array_equal(peaks.cpu().numpy(), want)
 
@@ -819,6 +822,7 @@ def test_stream_sync_falls_back_when_the_screen_is_not_selective():
     for pos in (3000, 120_000, 250_000, n - 500 - p.Lc):
         r[pos: pos + p.Lc] += 0.008 * c / np.abs(c).max()
     eng = engine_for(p, thresh=p.thresh)
+    eng.sync_stream_mode(2)
     x = torch.from_numpy(r).cuda()
     got = eng.sync_stream(x, cap=4096).cpu().numpy()
     assert eng.sync_stream_info()["path"] == 1
