@@ -1436,7 +1436,8 @@ static int build_screen_plan(gf3_ctx* c) {
     const int Q = (c->Lc + NC - 1) / NC;
     int H = (c->Lc + Q - 1) / Q;
     H += H & 1;                                          // even: the kernel stores lag pairs
-    if (Q > 16 || H > NC || c->Lc < 16) return GF3_OK;   // (outside the plan's range: fp64 path only)
+    if (Q > 16 || H > NC || H < 1024) return GF3_OK;      // (outside the plan's range: fp64 path only; scr_cells_kernel's block mask
+                                                        //  assumes at most 64 blocks under one workgroup's 57 346 lags)
     sp.Q = Q; sp.H = H;
     std::vector<float> Hs((size_t)Q * 8 * T * 4), H0N((size_t)Q * 2), Hinf(Q);
     for (int q = 0; q < Q; ++q) {
@@ -1970,7 +1971,7 @@ static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
         w.s_nblk = (w.plen + c->scr.H - 1) / c->scr.H;
         w.s_ncell = (w.nz + GF3_SCR_CELL - 1) / GF3_SCR_CELL;
         if (w.s_ncell < 1) w.s_ncell = 1;
-        w.s_nwg = (w.s_ncell + SCR_LIST_THREADS - 1) / SCR_LIST_THREADS;
+        w.s_nwg = (w.s_ncell + SCR_LIST_THREADS * SCR_LIST_GROUPS - 1) / (SCR_LIST_THREADS * SCR_LIST_GROUPS);
         w.s_capA = 4096 + 4 * (n / (c->Lc > 0 ? c->Lc : 1) + 1);   // every chirp of a clean stream peaks within the bound of the maximum
         w.s_capB = w.s_ncell / 16 > 4096 ? w.s_ncell / 16 : 4096;
         w.o_sblk = take((size_t)w.s_nblk * 8);                 // blk_max | blk_err (float each)

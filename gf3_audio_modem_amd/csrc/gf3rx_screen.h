@@ -324,6 +324,7 @@ __global__ void scr_mlo_kernel(const float* blk_max, const float* blk_err, int64
 // for cell 0 and the last lag for the last cell) has an upper bound P32 + E_b that reaches `level`.
 // pass 0 counts the listed cells per workgroup, pass 1 writes their numbers in ascending order.
 #define SCR_LIST_THREADS 256
+#define SCR_LIST_GROUPS 16           /* groups of 256 cells per workgroup: 4096 cells = 57 344 lags */
 __global__ __launch_bounds__(SCR_LIST_THREADS) void scr_cells_kernel(const float* __restrict__ P32, const float* __restrict__ blk_max,
                                                                      const float* __restrict__ blk_err, int H, int64_t plen, int64_t ncell,
                                                                      const ScrMisc* misc, int which, int64_t* counts,
@@ -332,39 +333,70 @@ __global__ __launch_bounds__(SCR_LIST_THREADS) void scr_cells_kernel(const float
     if (misc->status & 1) { if (!offsets && threadIdx.x == 0) counts[blockIdx.x] = 0; return; }
     if (offsets && counts[blockIdx.x] == 0) return;
     const double level = which == 0 ? misc->Mlo : misc->lim;
-    const int64_t c0 = (int64_t)blockIdx.x * SCR_LIST_THREADS;
-    // blocks touched by this workgroup's lags [14 c0, 14 (c0 + 256) + 2): skip everything when none can reach the level
-    if (!offsets) {
-        const int64_t mlo = GF3_SCR_CELL * c0, mhi = GF3_SCR_CELL * (c0 + SCR_LIST_THREADS) + 2;
-        bool any = false;
-        for (int64_t b = mlo / H; b <= (mhi - 1) / H && b * (int64_t)H < plen; ++b)
-            any = any || ((double)blk_max[b] + (double)blk_err[b] >= level) || !(level == level);
-        if (!any) { if (threadIdx.x == 0) counts[blockIdx.x] = 0; return; }
-    }
-    const int64_t c = c0 + threadIdx.x;
-    bool hit = false;
-    if (c < ncell) {
-        int64_t lo = GF3_SCR_CELL * c + 1, hi = lo + GF3_SCR_CELL;           // centres [lo, hi)
-        if (c == 0) lo = 0;
-        if (c == ncell - 1) hi = plen;
-        if (hi > plen) hi = plen;
-        for (int64_t m = lo; m < hi; ++m) {
-            const double up = (double)P32[m] + (double)blk_err[m / H];
-            hit = hit || (up >= level) || !(up == up);                      // (a NaN anywhere keeps the lag)
-        }
-        hit = hit || !(level == level);
-    }
-    const unsigned long long bal = __ballot(hit);
+    const bool all = !(level == level);                                      // NaN level: nothing can be excluded
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    int woff = 0, total = 0;
-    for (int w = 0; w < SCR_LIST_THREADS / 64; ++w) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
-    if (!offsets) { if (threadIdx.x == 0) counts[blockIdx.x] = total; return; }
-    if (hit) {
-        const int64_t o = offsets[blockIdx.x] + woff + __popcll(bal & ((1ull << lane) - 1ull));
-        if (o < cap) cells[o] = c;
+    // Which of the (at most 64) output blocks under this workgroup's lags can reach the level at all: one parallel
+    // look, shared through LDS.  In a stream with a chirp every 78 000 samples most workgroups leave right here.
+    __shared__ unsigned long long blkmask;
+    const int64_t b_first = (GF3_SCR_CELL * (int64_t)blockIdx.x * SCR_LIST_GROUPS * SCR_LIST_THREADS) / H;
+    if (wave == 0) {
+        const int64_t bb = b_first + lane;
+        const bool act = bb * (int64_t)H < plen && ((double)blk_max[bb] + (double)blk_err[bb] >= level);
+        const unsigned long long m = __ballot(act);
+        if (lane == 0) blkmask = all ? ~0ull : m;
     }
+    __syncthreads();
+    const unsigned long long bm = blkmask;
+    if (bm == 0) { if (!offsets && threadIdx.x == 0) counts[blockIdx.x] = 0; return; }
+    int64_t run = offsets ? offsets[blockIdx.x] : 0;                         // cells listed so far (uniform)
+    for (int g = 0; g < SCR_LIST_GROUPS; ++g) {
+        const int64_t c0 = ((int64_t)blockIdx.x * SCR_LIST_GROUPS + g) * SCR_LIST_THREADS;
+        if (c0 >= ncell) break;
+        // blocks touched by this group's lags [14 c0, 14 (c0 + 256) + 2): skip the group when none can reach the level
+        // (32-bit arithmetic relative to the workgroup's first block: 64-bit divisions are long scalar sequences)
+        const unsigned rel0 = (unsigned)(GF3_SCR_CELL * c0 - b_first * (int64_t)H);
+        const int r0 = (int)(rel0 / (unsigned)H), r1 = (int)((rel0 + GF3_SCR_CELL * SCR_LIST_THREADS + 1) / (unsigned)H);
+        const unsigned long long span = (r1 >= 63 ? ~0ull : ((1ull << (r1 + 1)) - 1ull)) & ~((1ull << r0) - 1ull);
+        if (!(bm & span)) continue;                                          // (uniform)
+        const int64_t c = c0 + threadIdx.x;
+        bool hit = false;
+        if (c < ncell) {
+            int64_t lo = GF3_SCR_CELL * c + 1, hi = lo + GF3_SCR_CELL;       // centres [lo, hi)
+            if (c == 0) lo = 0;
+            if (c == ncell - 1) hi = plen;
+            if (hi > plen) hi = plen;
+            // block of the first lag by one 32-bit division relative to the workgroup's first block; at most one
+            // boundary can fall inside a cell (H >= 1024 > 16)
+            const unsigned rel = (unsigned)(lo - b_first * (int64_t)H);
+            int64_t bb = b_first + rel / (unsigned)H;
+            int64_t bend = (bb + 1) * (int64_t)H;
+            const float e0 = blk_err[bb];
+            const float e1 = (bend < hi) ? blk_err[bb + 1] : e0;
+            // all (at most 16) lags are fetched before any is looked at: a short-circuiting loop would serialise
+            // sixteen HBM round trips
+            float pv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) pv[j] = (lo + j < hi) ? P32[lo + j] : -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double up = (double)pv[j] + (double)((lo + j >= bend) ? e1 : e0);
+                hit = hit | ((lo + j < hi) & ((up >= level) | !(up == up)));  // (a NaN anywhere keeps the lag)
+            }
+            hit = hit || all;
+        }
+        const unsigned long long bal = __ballot(hit);
+        __syncthreads();                                                     // the previous group's wsum has been read
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < SCR_LIST_THREADS / 64; ++w) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+        if (offsets && hit) {
+            const int64_t o = run + woff + __popcll(bal & ((1ull << lane) - 1ull));
+            if (o < cap) cells[o] = c;
+        }
+        run += total;
+    }
+    if (!offsets && threadIdx.x == 0) counts[blockIdx.x] = run;
 }
 
 // total of a cell list -> misc, overflow -> status
