@@ -163,3 +163,38 @@ def test_chunked_matched_filter_equals_the_one_shot_form():
         Q = orc.matched_filter_chunked(g["r"], p, log2_fft=lf, workers=2)
         assert Q.shape == P.shape and np.abs(P - Q).max() <= 1e-13 * np.abs(P).max()
         assert np.array_equal(np.flatnonzero(orc.pick_peaks(Q, p.Lc, len(g["r"]), p.thresh)), g["peaks"])
+
+
+def test_numpy_complex_abs_formula_restated_by_the_engine():
+    """The hard demapper's ties hinge on how `abs(symbols - constellation)` (OFDM.py:490) rounds.  NumPy's complex128
+    `absolute` loop evaluates larger * sqrt(fma(r, r, 1)), r = smaller / larger -- NOT a correctly rounded hypot -- and
+    gf3rx_device.h:np_cabs restates exactly that.  Here the formula is evaluated with an exact-rational fma and compared
+    bit for bit with np.abs on fixture distances (ties included), so that the model the device code follows is pinned
+    on the CPU as well; a correctly rounded hypot is shown to differ on some of them."""
+    import math
+    from fractions import Fraction
+    g = load("g5_demap_edges")
+    sym, pts = g["sym6"], g["pts6"]
+    sym = sym[np.isfinite(sym.real) & np.isfinite(sym.imag)]
+    d = (sym[-400:, None] - pts[None, :]).reshape(-1)                        # the exact-tie block and its neighbours
+    ref = np.abs(d)
+
+    def fma(a, b, c):
+        f = Fraction(a) * Fraction(b) + Fraction(c)
+        return f.numerator / f.denominator                                   # int / int is correctly rounded
+
+    def model(z):
+        re, im = abs(z.real), abs(z.imag)
+        la, sm = max(re, im), min(re, im)
+        r = 0.0 if la == 0.0 else sm / la
+        return math.sqrt(fma(r, r, 1.0)) * la
+
+    got = np.array([model(z) for z in d])
+    if not np.array_equal(got, ref):                                         # a host without FMA evaluates r*r + 1 unfused
+        unfused = np.array([math.sqrt((min(abs(z.real), abs(z.imag)) / max(abs(z.real), abs(z.imag))) ** 2 + 1.0)
+                            * max(abs(z.real), abs(z.imag)) if z != 0 else 0.0 for z in d])
+        if np.array_equal(unfused, ref):
+            pytest.skip("this host's NumPy evaluates the formula without FMA; the fixtures were written on an FMA host")
+    assert np.array_equal(got, ref)
+    hyp = np.array([math.hypot(z.real, z.imag) for z in d])                  # libm hypot (correctly rounded here)
+    assert (hyp != ref).any()
