@@ -1975,7 +1975,7 @@ static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
         w.s_capA = 4096 + 4 * (n / (c->Lc > 0 ? c->Lc : 1) + 1);   // every chirp of a clean stream peaks within the bound of the maximum
         w.s_capB = w.s_ncell / 16 > 4096 ? w.s_ncell / 16 : 4096;
         w.o_sblk = take((size_t)w.s_nblk * 8);                 // blk_max | blk_err (float each)
-        w.o_smisc = take(sizeof(ScrMisc));
+        w.o_smisc = take(sizeof(ScrMisc) + 16);                // (+ the screen's running lower bound of the maximum)
         w.o_cellA = take((size_t)w.s_capA * 8);
         w.o_cmaxA = take((size_t)w.s_capA * 8);
         w.o_cellB = take((size_t)w.s_capB * 8);
@@ -2016,10 +2016,12 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
     int64_t* offB = (int64_t*)(base + w.o_offB);
     const int dt = c->cfg.in_dtype;
     {
+        int* run_lo = (int*)(base + w.o_smisc + sizeof(ScrMisc));       // running lower bound of the maximum (float bits; 0 = none yet)
+        HIPCHK(c, hipMemsetAsync(run_lo, 0, sizeof(int), st));
         ScreenArgs a{d_r, n, dt, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, w.s_nblk, w.plen,
-                     P32, blk_max, blk_err};
-        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 4 * GF3_SCR_B) * sizeof(float);
-        const int64_t grid = (w.s_nblk + GF3_SCR_B - 1) / GF3_SCR_B;
+                     P32, blk_max, blk_err, run_lo, (float)c->cfg.thresh};
+        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 5 * GF3_SCR_B + 4) * sizeof(float);
+        const int64_t grid = (((w.s_nblk + GF3_SCR_B - 1) / GF3_SCR_B + 7) / 8) * 8;      // padded to the 8 XCDs (scr_ols_kernel's block order)
         hipError_t e = hipSuccess;
         DISPATCH_DT(dt, e = launch((scr_ols_kernel<DTC>), grid, GF3_SCR_T, lds, st, a));
         HIPCHK(c, e);
@@ -2082,10 +2084,10 @@ extern "C" int gf3_debug_stream_screen(gf3_ctx* c, const void* d_r, int64_t n, f
     const int64_t plen = n + c->Lc - 1, nblk = (plen + sp.H - 1) / sp.H;
     *h_hop = sp.H;
     ScreenArgs a{d_r, n, c->cfg.in_dtype, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, nblk, plen,
-                 d_p32, d_blk, d_blk + nblk};
-    const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 4 * GF3_SCR_B) * sizeof(float);
+                 d_p32, d_blk, d_blk + nblk, nullptr, 0.0f};                 // (no skipping: the tests look at every lag)
+    const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 5 * GF3_SCR_B + 4) * sizeof(float);
     hipError_t e = hipSuccess;
-    DISPATCH_DT(a.dt, e = launch((scr_ols_kernel<DTC>), (nblk + GF3_SCR_B - 1) / GF3_SCR_B, GF3_SCR_T, lds, (hipStream_t)stream, a));
+    DISPATCH_DT(a.dt, e = launch((scr_ols_kernel<DTC>), (((nblk + GF3_SCR_B - 1) / GF3_SCR_B + 7) / 8) * 8, GF3_SCR_T, lds, (hipStream_t)stream, a));
     HIPCHK(c, e);
     return GF3_OK;
 }

@@ -119,6 +119,8 @@ struct ScreenArgs {
     float* P32;                // [plen]
     float* blk_max;            // [nblk] max of the block's P32
     float* blk_err;            // [nblk] bound on |P32 - P| for every lag of the block
+    int* run_lo;               // optional: running lower bound of the maximum (float bits, > 0), shared by the grid
+    float thresh;              // 0 < thresh < 1 enables skipping the store of blocks that cannot matter
 };
 
 // one window: samples -> spectrum slots.  X[2r] = X[k_r], X[2r+1] = X[4096 - k_r], k_r = t + 256 r (thread 0, r = 0:
@@ -190,7 +192,14 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
     float* nrm = (float*)(bufB + NC);                 // [32][4] per-window, per-wave energy
     float* red = nrm + 128;                           // [B][4] per-block, per-wave maximum
     const int t = threadIdx.x, wave = t >> 6;
-    const int64_t b0 = (int64_t)B * blockIdx.x;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 share one, each with its own L2),
+    // and neighbouring groups of blocks share 5 of their 9 windows.  So the XCD that gets blockIdx % 8 == x walks its
+    // own contiguous eighth of the stream: the windows a workgroup re-reads were fetched by its predecessor on the SAME
+    // L2 a moment ago, instead of by another XCD.  (Placement is a speed matter only; any order is correct.)
+    const int64_t per_xcd = (int64_t)(gridDim.x >> 3);                 // the host pads the grid to a multiple of 8
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t b0 = (int64_t)B * wg;
+    if (b0 >= a.nblk) return;                                          // (uniform: padding workgroups)
     cf tw2 = a.tw[(t & 15) * 16], tw3 = a.tw[t], wb = a.twn[t];
     // Made opaque before every transform: otherwise LLVM hoists all 30 twiddle powers of the two passes and the
     // eight split twiddles out of the window loop and keeps ~80 registers of them live across it.
@@ -232,12 +241,24 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
             }
         }
     }
-    // ---- per block: inverse real FFT of the Hermitian spectrum, store, maximum
+    // ---- per block: error bound, inverse real FFT of the Hermitian spectrum, maximum, store
+    float* berr = red + 4 * B;                        // [B] the blocks' error bounds, [B]: the grid's running bound as read for the current block
+    lds_barrier();
+    if (t < B) {
+        float e = 0.0f;
+        for (int q = 0; q < a.Q; ++q) {
+            const float* n4 = nrm + (t + q) * 4;
+            const float n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
+            e = fmaf(a.Hinf[q], sqrtf(n2) * 1.0001f, e);
+        }
+        berr[t] = e * GF3_SCR_GAMMA * 1.0001f + 1e-37f;
+    }
     const float inv = 0.25f / (float)NC;              // 1/NC of the inverse transform, 1/2 of each of the two splits
     const float c32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
                           0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
     const float s32[8] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
                           0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f};
+    const bool may_skip = a.run_lo != nullptr && a.thresh > 0.0f && a.thresh < 1.0f;
 #pragma unroll
     for (int g = 0; g < B; ++g) {
         const int64_t m0 = (b0 + g) * (int64_t)a.H;
@@ -273,31 +294,38 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
                 const int i = 2 * (t + 256 * m);
                 const cf z = v[scr_perm(m)];
                 const float y0 = z.x * inv, y1 = -z.y * inv;
-                if (i + 1 < W) {
-                    *(float2*)(a.P32 + m0 + i) = make_float2(y0, y1);
-                    mx = fmaxf(mx, fmaxf(y0, y1));
-                } else if (i < W) {
-                    a.P32[m0 + i] = y0;
-                    mx = fmaxf(mx, y0);
-                }
+                if (i + 1 < W) mx = fmaxf(mx, fmaxf(y0, y1));
+                else if (i < W) mx = fmaxf(mx, y0);
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
             if ((t & 63) == 0) red[g * 4 + wave] = mx;
-        }
-    }
-    lds_barrier();
-    if (t < B) {
-        const int64_t blk = b0 + t;
-        if (blk < a.nblk) {
-            a.blk_max[blk] = fmaxf(fmaxf(red[t * 4], red[t * 4 + 1]), fmaxf(red[t * 4 + 2], red[t * 4 + 3]));
-            float e = 0.0f;
-            for (int q = 0; q < a.Q; ++q) {
-                const float* n4 = nrm + (t + q) * 4;
-                const float n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
-                e = fmaf(a.Hinf[q], sqrtf(n2) * 1.0001f, e);
+            // (one lane reads the shared bound -- 256 lanes hammering one address would serialise the whole grid)
+            if (t == 0) berr[B] = may_skip ? __int_as_float(__atomic_load_n(a.run_lo, __ATOMIC_RELAXED)) : 0.0f;
+            lds_barrier();
+            const float bmax = fmaxf(fmaxf(red[g * 4], red[g * 4 + 1]), fmaxf(red[g * 4 + 2], red[g * 4 + 3]));
+            const float be = berr[g];
+            const float run = berr[B];
+            // A block whose upper bound stays below thresh x (a lower bound of the maximum already established by
+            // any workgroup) can hold neither the maximum nor a candidate, whatever the final maximum turns out to
+            // be (it can only be larger): its lags are never read again and need not be written.
+            const bool skip = may_skip && run > 0.0f && (bmax + be) < a.thresh * run * (1.0f - 1e-6f) * 0.9999f;
+            if (!skip) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) {
+                    const int i = 2 * (t + 256 * m);
+                    const cf z = v[scr_perm(m)];
+                    const float y0 = z.x * inv, y1 = -z.y * inv;
+                    if (i + 1 < W) *(float2*)(a.P32 + m0 + i) = make_float2(y0, y1);
+                    else if (i < W) a.P32[m0 + i] = y0;
+                }
             }
-            a.blk_err[blk] = e * GF3_SCR_GAMMA * 1.0001f + 1e-37f;
+            if (t == 0) {
+                a.blk_max[b0 + g] = bmax;
+                a.blk_err[b0 + g] = be;
+                const float lo = bmax - be;
+                if (a.run_lo && lo > 0.0f && lo > run) atomicMax(a.run_lo, __float_as_int(lo));   // positive floats order like their bits; rare once a chirp has been seen
+            }
         }
     }
 }
@@ -372,15 +400,18 @@ __global__ __launch_bounds__(SCR_LIST_THREADS) void scr_cells_kernel(const float
             int64_t bend = (bb + 1) * (int64_t)H;
             const float e0 = blk_err[bb];
             const float e1 = (bend < hi) ? blk_err[bb + 1] : e0;
+            // a lag counts only if its own block can reach the level: blocks that cannot were possibly never written
+            const bool a0 = all | ((double)blk_max[bb] + (double)e0 >= level);
+            const bool a1 = (bend < hi) ? (all | ((double)blk_max[bb + 1] + (double)e1 >= level)) : a0;
             // all (at most 16) lags are fetched before any is looked at: a short-circuiting loop would serialise
             // sixteen HBM round trips
             float pv[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) pv[j] = (lo + j < hi) ? P32[lo + j] : -INFINITY;
+            for (int j = 0; j < 16; ++j) pv[j] = (lo + j < hi && ((lo + j >= bend) ? a1 : a0)) ? P32[lo + j] : -INFINITY;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const double up = (double)pv[j] + (double)((lo + j >= bend) ? e1 : e0);
-                hit = hit | ((lo + j < hi) & ((up >= level) | !(up == up)));  // (a NaN anywhere keeps the lag)
+                hit = hit | ((lo + j < hi) & ((lo + j >= bend) ? a1 : a0) & ((up >= level) | !(up == up)));  // (a NaN keeps the lag)
             }
             hit = hit || all;
         }
