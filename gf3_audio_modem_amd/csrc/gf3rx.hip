@@ -749,7 +749,8 @@ struct OlsArgs {
     cplx* spec;               // [NWIN][NC+1]
     int64_t nwin, plen;
     double* corr;
-    double* part;             // [ols grid] maximum of the lags each workgroup wrote (the global max is max over these)
+    double* part;             // [ols work items] maximum of the lags each workgroup wrote (the global max is max over these)
+    int64_t nitems;           // logical work items of the launch (windows for spec_kernel, groups of OLS_B blocks for ols_kernel)
 };
 
 template <int NC, int DT>
@@ -758,7 +759,8 @@ __global__ __launch_bounds__(NC / 8, 2) void spec_kernel(OlsArgs a) {
     constexpr int T = NC / 8;
     typedef typename RawT<DT>::E E;
     const int tid = threadIdx.x;
-    const int64_t j = blockIdx.x;
+    const int64_t j = xcd_order(blockIdx.x, gridDim.x);     // neighbouring windows overlap by N - H samples: same XCD, same L2
+    if (j >= a.nitems) return;
     const int64_t seg = j * (int64_t)a.H - (a.Lc - 1);
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
@@ -798,7 +800,9 @@ __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
     constexpr int T = NC / 8, B = OLS_B;
     cplx* lds = smem;
     const int tid = threadIdx.x;
-    const int64_t b = B * (int64_t)blockIdx.x;
+    const int64_t item = xcd_order(blockIdx.x, gridDim.x);  // neighbouring groups share Q - 1 of their windows: same XCD, same L2
+    if (item >= a.nitems) return;
+    const int64_t b = B * item;
     FftTw<NC> ft;
     ft.init(tid, a.t.tw);
     cplx wb = a.t.twn[tid];
@@ -869,7 +873,7 @@ __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
         }
     }
     mx = block_max(mx, (double*)lds);                 // (starts with a barrier: every wave is done reading yb)
-    if (tid == 0) a.part[blockIdx.x] = mx;
+    if (tid == 0) a.part[item] = mx;
 }
 
 // ============================================================================
@@ -2136,15 +2140,18 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
         a.spec = (cplx*)(base + w.o_spec); a.nwin = w.nwin; a.plen = w.plen; a.corr = P; a.part = part;
         const size_t lds = fft_lds_bytes(pl.NC);
         hipError_t e = hipSuccess;
-        DISPATCH_NC(pl.NC, a.dt, e = launch((spec_kernel<NCC, DTC>), w.nwin, NCC / 8, lds, st, a));
+        auto pad8 = [](int64_t x) { return (x + 7) / 8 * 8; };              // grids padded to the 8 XCDs (xcd_order)
+        a.nitems = w.nwin;
+        DISPATCH_NC(pl.NC, a.dt, e = launch((spec_kernel<NCC, DTC>), pad8(w.nwin), NCC / 8, lds, st, a));
         HIPCHK(c, e);
+        a.nitems = (w.nblk + OLS_B - 1) / OLS_B;
         switch (pl.NC) {
 #ifndef GF3_DEV_BUILD
-            case 512:  e = launch(ols_kernel<512>, (w.nblk + OLS_B - 1) / OLS_B, 64, lds, st, a); break;
-            case 1024: e = launch(ols_kernel<1024>, (w.nblk + OLS_B - 1) / OLS_B, 128, lds, st, a); break;
-            case 4096: e = launch(ols_kernel<4096>, (w.nblk + OLS_B - 1) / OLS_B, 512, lds, st, a); break;
+            case 512:  e = launch(ols_kernel<512>, pad8(a.nitems), 64, lds, st, a); break;
+            case 1024: e = launch(ols_kernel<1024>, pad8(a.nitems), 128, lds, st, a); break;
+            case 4096: e = launch(ols_kernel<4096>, pad8(a.nitems), 512, lds, st, a); break;
 #endif
-            default:   e = launch(ols_kernel<2048>, (w.nblk + OLS_B - 1) / OLS_B, 256, lds, st, a); break;
+            default:   e = launch(ols_kernel<2048>, pad8(a.nitems), 256, lds, st, a); break;
         }
         HIPCHK(c, e);
     }

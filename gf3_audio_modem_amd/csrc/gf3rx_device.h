@@ -66,6 +66,12 @@ GF3_DEV double np_cabs(double x, double y) {
 // loads stay in flight across the barrier (their consumers get their own s_waitcnt).
 GF3_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// XCD-aware work order for kernels whose neighbouring workgroups re-read each other's data: workgroups are dealt
+// round-robin over the 8 XCDs (blockIdx % 8 share one XCD and its L2), so logical work item
+// (blockIdx % 8) * (grid / 8) + blockIdx / 8 makes every XCD walk a contiguous eighth of the items.  The grid must be a
+// multiple of 8 (pad; padded items return).  Placement is a speed matter only.
+GF3_DEV int64_t xcd_order(unsigned bid, unsigned grid) { return (int64_t)(bid & 7u) * (int64_t)(grid >> 3) + (int64_t)(bid >> 3); }
+
 // Opaque copy of a per-thread index.  Everything derived from the copy is recomputed where it
 // is used instead of being hoisted out of the symbol loop and kept live (or spilled) across it.
 GF3_DEV int launder(int x) { asm volatile("" : "+v"(x)); return x; }

@@ -196,9 +196,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
     // and neighbouring groups of blocks share 5 of their 9 windows.  So the XCD that gets blockIdx % 8 == x walks its
     // own contiguous eighth of the stream: the windows a workgroup re-reads were fetched by its predecessor on the SAME
     // L2 a moment ago, instead of by another XCD.  (Placement is a speed matter only; any order is correct.)
-    const int64_t per_xcd = (int64_t)(gridDim.x >> 3);                 // the host pads the grid to a multiple of 8
-    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int64_t b0 = (int64_t)B * wg;
+    const int64_t b0 = (int64_t)B * xcd_order(blockIdx.x, gridDim.x);  // (the host pads the grid to a multiple of 8)
     if (b0 >= a.nblk) return;                                          // (uniform: padding workgroups)
     cf tw2 = a.tw[(t & 15) * 16], tw3 = a.tw[t], wb = a.twn[t];
     // Made opaque before every transform: otherwise LLVM hoists all 30 twiddle powers of the two passes and the
