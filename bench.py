@@ -237,7 +237,7 @@ def config5_rooflines(dev, log2_samples=28, log2_symbols=26, reps=5):
     hard, _ = eng.demap_hard(sym[: 1 << 20])
     sign_ok = bool(torch.equal((llr[: 1 << 20] < 0).to(torch.uint8), hard))
     by = n * (16 + 4 * 6)
-    out["roofline_soft_demap"] = {"kernel": "soft_demap_sep_kernel<6> (64-QAM)", "bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
+    out["roofline_soft_demap"] = {"kernel": "soft_demap_bin_kernel<3,3> (64-QAM)", "bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by,
                                   "avg_launch_ms": ms, "symbols_per_launch": n, "sign_equals_hard_decision": sign_ok}
     eng.close()

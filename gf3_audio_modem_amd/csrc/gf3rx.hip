@@ -1140,6 +1140,62 @@ __global__ __launch_bounds__(256) void soft_demap_sep_kernel(DemapArgs a) {
     }
 }
 
+// The same for the tables every square Gray QAM generator produces (and the reference's QPSK): 2^HI x 2^HQ grid, the
+// first HI label bits are the binary index of the I level in `lvI`, the last HQ bits that of the Q level.  Which
+// levels carry a 1 in which bit is then known at compile time, so the whole reduction is straight-line v_min_f64 --
+// no scalar bit tests, no branches (the generic kernel above spends more time steering than computing: 48 scalar
+// branches per symbol against 48 minima).
+template <int HI, int HQ>
+__global__ __launch_bounds__(256) void soft_demap_bin_kernel(DemapArgs a) {
+    constexpr int MU = HI + HQ, NI = 1 << HI, NQ = 1 << HQ;
+    double lvI[NI], lvQ[NQ];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) lvI[k] = a.sep.lvI[k];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) lvQ[k] = a.sep.lvQ[k];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cplx e = a.sym[i];
+        double dI[NI], dQ[NQ];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) { const double t = e.x - lvI[k]; dI[k] = t * t; }
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) { const double t = e.y - lvQ[k]; dQ[k] = t * t; }
+        float out[MU];
+#pragma unroll
+        for (int b = 0; b < HI; ++b) {                 // label bit b = bit (HI - 1 - b) of the I index
+            double m0 = INFINITY, m1 = INFINITY;
+#pragma unroll
+            for (int k = 0; k < NI; ++k) { if ((k >> (HI - 1 - b)) & 1) m1 = fmin(m1, dI[k]); else m0 = fmin(m0, dI[k]); }
+            out[b] = (float)((m1 - m0) * a.inv_nv);
+        }
+#pragma unroll
+        for (int b = 0; b < HQ; ++b) {
+            double m0 = INFINITY, m1 = INFINITY;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) { if ((k >> (HQ - 1 - b)) & 1) m1 = fmin(m1, dQ[k]); else m0 = fmin(m0, dQ[k]); }
+            out[HI + b] = (float)((m1 - m0) * a.inv_nv);
+        }
+        if constexpr (MU % 4 == 0) {
+#pragma unroll
+            for (int b = 0; b < MU; b += 4) *(float4*)(a.llr + i * MU + b) = make_float4(out[b], out[b + 1], out[b + 2], out[b + 3]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < MU; b += 2) *(float2*)(a.llr + i * MU + b) = make_float2(out[b], out[b + 1]);
+        }
+    }
+}
+// is the separable table of that binary-indexed kind?
+static bool sep_is_binary(const SepTab& sp, int mu, int& hI, int& hQ) {
+    hI = hQ = 0;
+    while ((1 << hI) < sp.nI) ++hI;
+    while ((1 << hQ) < sp.nQ) ++hQ;
+    if (sp.nI < 2 || sp.nQ < 2 || (1 << hI) != sp.nI || (1 << hQ) != sp.nQ || hI + hQ != mu || hI != hQ) return false;
+    if (sp.maskI != (((1 << hI) - 1) << hQ)) return false;
+    for (int k = 0; k < sp.nI; ++k) if (sp.labI[k] != (k << hQ)) return false;
+    for (int k = 0; k < sp.nQ; ++k) if (sp.labQ[k] != k) return false;
+    return true;
+}
+
 // ============================================================================
 // transmit-side synthesiser: one packet per workgroup
 // transmitter.map / build_OFDM_symbol / ifft / add_cp / send_to_stream (OFDM.py:196-259)
@@ -2229,8 +2285,15 @@ static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, ui
     int64_t grid = (n + 255) / 256;
     if (grid > 256 * 16) grid = 256 * 16;
     if (grid < 1) return GF3_OK;
+    int hI = 0, hQ = 0;
     if (bits) hipLaunchKernelGGL(demap_hard_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
-    else if (c->sep.nI > 0) {
+    else if (c->sep.nI > 0 && sep_is_binary(c->sep, c->cfg.mu, hI, hQ) && hI <= 3) {
+        switch (hI) {                                  // QPSK, 16-QAM, 64-QAM: straight-line minima
+            case 1: hipLaunchKernelGGL((soft_demap_bin_kernel<1, 1>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+            case 2: hipLaunchKernelGGL((soft_demap_bin_kernel<2, 2>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+            default: hipLaunchKernelGGL((soft_demap_bin_kernel<3, 3>), dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
+        }
+    } else if (c->sep.nI > 0) {
         switch (c->cfg.mu) {
             case 1: hipLaunchKernelGGL(soft_demap_sep_kernel<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;
             case 2: hipLaunchKernelGGL(soft_demap_sep_kernel<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a); break;

@@ -865,3 +865,23 @@ def test_known_channel_zero_forcing(mu, dt):
     assert np.array_equal(bits.cpu().numpy(), ref_bits)
     if dt == torch.float64:
         assert np.array_equal(bits.cpu().numpy().reshape(-1), payload)       # noiseless + known channel => BER 0
+
+
+@pytest.mark.parametrize("mu", [4, 6])
+def test_soft_demap_generic_grid_kernel(mu):
+    """Square Gray QAM whose label bits are listed in reverse order (the Q axis owns the leading bits): still a
+    separable grid, but not the binary-indexed layout the straight-line kernel is specialised for -- the scalar-steered
+    generic grid kernel runs.  LLRs against the oracle's max-log formula, signs against the hard decisions."""
+    pts, bt = orc.square_qam_table(mu)
+    bt = bt[:, ::-1].copy()
+    p = orc.RxParams(N=1024, CP=0, P=1, D=1, lo=1, hi=511, const_points=pts, const_bits=bt.astype(np.int64),
+                     known_bits=np.zeros(511 * mu, np.uint8), fit_lo=10, fit_hi=100)
+    eng = engine_for(p)
+    rs = np.random.RandomState(mu)
+    sym = pts[rs.randint(0, len(pts), 5000)] + 0.1 * (rs.randn(5000) + 1j * rs.randn(5000))
+    llr = eng.soft_demap(sym, 0.02).cpu().numpy()
+    ref = orc.soft_demap_maxlog(sym, 0.02, p)
+    np.testing.assert_allclose(llr, ref.astype(np.float32), rtol=2e-6, atol=1e-6)
+    hard, _ = eng.demap_hard(sym)
+    assert np.array_equal((llr < 0).astype(np.uint8), hard.cpu().numpy())
+    assert np.array_equal(hard.cpu().numpy(), orc.demap_hard(sym, p)[0])

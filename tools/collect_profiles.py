@@ -68,7 +68,7 @@ def main():
     F = bench["config"]["frames_per_gpu"]
     algo = {"demod_kernel<2048, 1, false, 2>": bench["roofline"]["algorithmic_bytes_per_launch"],
             "corr_kernel<1024, 1>": bench["roofline_sync"]["algorithmic_bytes_per_launch"]}
-    for k, leg in (("demod_kernel<2048, 1, false, 1>", "roofline_demod_16qam"), ("soft_demap_sep_kernel<6>", "roofline_soft_demap")):
+    for k, leg in (("demod_kernel<2048, 1, false, 1>", "roofline_demod_16qam"), ("soft_demap_bin_kernel<3, 3>", "roofline_soft_demap")):
         if leg in bench:
             algo[k] = bench[leg]["algorithmic_bytes_per_launch"]
     for N, leg in bench.get("roofline_rfft", {}).items():
