@@ -1,5 +1,6 @@
 #!/bin/bash
-# Run ON THE GPU BOX from the repo root: bench line, rocprofv3 kernel stats of the same command, HBM-traffic counters
+# Run ON THE GPU BOX from the repo root (delete the local gpurun_out/round first: gpurun MERGES scratch output, and the
+# collector averages every CSV it finds there): bench line, rocprofv3 kernel stats of the same command, HBM-traffic counters
 # (separate --pmc passes, as the microarch guide prescribes) and one SQ pass (issue / wait / LDS shares of the hot kernels).
 set -o pipefail
 R=$PWD; OUT=$R/gpurun_out/round; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
