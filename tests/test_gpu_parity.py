@@ -885,3 +885,41 @@ def test_soft_demap_generic_grid_kernel(mu):
     hard, _ = eng.demap_hard(sym)
     assert np.array_equal((llr < 0).astype(np.uint8), hard.cpu().numpy())
     assert np.array_equal(hard.cpu().numpy(), orc.demap_hard(sym, p)[0])
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_stream_sync_degenerate_streams(mode):
+    """Streams shorter than a chirp, all-zero streams (P = 0 everywhere: the reference divides 0 by 0 and finds nothing)
+    and a lone partial chirp, through the all-fp64 path (mode 1) and the screened path (mode 2): the oracle's peaks."""
+    import warnings
+    g = load("g1_n1024_qpsk")
+    p = params_of(g)
+    c = orc.chirp_replica(p)
+    rs = np.random.RandomState(9)
+    cases = [np.zeros(50), np.zeros(3 * p.Lc), rs.randn(37), rs.randn(p.Lc // 3),
+             np.concatenate([np.zeros(10), c[: p.Lc // 2], np.zeros(500)]),
+             np.concatenate([np.zeros(700), c, np.zeros(2)]), np.concatenate([np.zeros(700), c, np.zeros(1)])]
+    eng = engine_for(p)
+    eng.sync_stream_mode(mode)
+    for r in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = np.flatnonzero(orc.chirp_method(r, p))
+        got = eng.sync_stream(torch.from_numpy(r).cuda()).cpu().numpy()
+        assert np.array_equal(got, want), (mode, len(r), got, want)
+
+
+def test_new_abi_error_paths():
+    """gf3_sync_stream_mode / gf3_equalise_known_h reject what the header says they reject."""
+    g = load("g1_n1024_qpsk")
+    eng = engine_for(params_of(g))
+    for bad in (-1, 3):
+        with pytest.raises(ValueError, match="mode"):
+            eng.sync_stream_mode(bad)
+    x = torch.zeros(5000, dtype=torch.float64, device="cuda")
+    with pytest.raises(ValueError, match="n_taps"):
+        eng.equalise_known_h(x, [0], np.zeros(0))
+    with pytest.raises(ValueError, match="n_taps"):
+        eng.equalise_known_h(x, [0], np.ones(5000))
+    eq, bits, idx = eng.equalise_known_h(x, [], np.ones(3))                    # no symbols: nothing to do
+    assert eq.shape[0] == 0
