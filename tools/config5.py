@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""BASELINE config 5: batched real FFT for N in {1024, 2048, 4096, 8192} (2^24 real samples
+"""Quick look at BASELINE config 5 on a CACHE-RESIDENT working set (201 MB per N fits the 256 MB Infinity Cache, so the
+GB/s printed here are not HBM figures: the roofline numbers come from bench.py's config-5 leg, 2^28 samples per N,
+`roofline_rfft` / `roofline_soft_demap`).  Batched real FFT for N in {1024, 2048, 4096, 8192} (2^24 real samples
 each, RandomState(5).randn, f32 storage) + 64-QAM soft demapping of 2^24 symbols; reports
 kernel time and achieved algorithmic HBM GB/s (B_in*N in + 16*(N/2+1) out per
 transform; 16 B in + 4*mu B out per symbol).  Also the known-byte-count workload used to
