@@ -1322,10 +1322,12 @@ struct gf3_ctx {
     unsigned long long* stamps = nullptr;
     int contig_lo = 0;
     int device = 0;                     // HIP device the context (tables, plans) lives on
+    int n_cu = 256;                     // its compute units (grid sizing of the persistent-style kernels)
     // single-precision screening plan of the stream-mode sync (gf3rx_screen.h); ok = false: always the fp64 path
     struct { bool ok = false; int Q = 0, H = 0; cf *d_tw = nullptr, *d_twn = nullptr; float4* d_Hs = nullptr;
-             float *d_H0N = nullptr, *d_Hinf = nullptr; } scr;
-    int stream_mode = 0;                // 0: by stream length (screen from GF3_SCR_MIN_SAMPLES on); 1: fp64 only; 2: screen whenever a plan exists
+             float *d_H0N = nullptr, *d_Hinf = nullptr;
+             bool ring = false; float4* d_Hb = nullptr; float* d_ecoef = nullptr; int R_forced = 0; } scr;   // band-limited kernel (scr_ring_kernel)
+    int stream_mode = 0;                // 0: by stream length (screen from GF3_SCR_MIN_SAMPLES on); 1: fp64 only; 2: screen whenever a plan exists; 3: as 2 with the general kernel
     int64_t last_info[4] = {0, 0, 0, 0};   // last gf3_sync_stream: path taken (0 screened, 1 fp64 after fallback, 2 fp64), cells A, cells B, candidates
     std::vector<double> chirp;
     std::vector<cplx> known_pts;
@@ -1500,6 +1502,11 @@ static int build_screen_plan(gf3_ctx* c) {
                                                         //  assumes at most 64 blocks under one workgroup's 57 346 lags)
     sp.Q = Q; sp.H = H;
     std::vector<float> Hs((size_t)Q * 8 * T * 4), H0N((size_t)Q * 2), Hinf(Q);
+    // band-limited kernel: the kept bins in its slot order, and per partition the error per unit |x|_2 -- rounding
+    // (GF3_SCR_GAMMA max|H_q|) plus the 2-norm of what the dropped bins |k| >= 256 KS hold (gf3rx_screen.h)
+    constexpr int KS = GF3_SCR_KS;
+    std::vector<float> Hb((size_t)Q * (KS / 2) * T * 4), ecoef(Q);
+    double hout_sum = 0.0, hall_sum = 0.0;
     for (int q = 0; q < Q; ++q) {
         std::vector<double> re(N, 0.0), im(N, 0.0);
         for (int k = 0; k < H && q * H + k < c->Lc; ++k) re[k] = c->chirp[(size_t)q * H + k];
@@ -1514,7 +1521,22 @@ static int build_screen_plan(gf3_ctx* c) {
                 float* o = &Hs[(((size_t)q * 8 + r) * T + t) * 4];
                 o[0] = (float)re[k]; o[1] = (float)im[k]; o[2] = (float)re[NC - k]; o[3] = (float)im[NC - k];
             }
+        for (int p = 0; p < KS / 2; ++p)
+            for (int t = 0; t < T; ++t) {
+                const int k = t + 512 * p;
+                float* o = &Hb[(((size_t)q * (KS / 2) + p) * T + t) * 4];
+                o[0] = (float)re[k]; o[1] = (float)im[k]; o[2] = (float)re[k + 256]; o[3] = (float)im[k + 256];
+            }
+        double out2 = re[NC] * re[NC] + im[NC] * im[NC], all2 = 0.0;       // two-sided sums over the N bins of the real window
+        for (int k = 256 * KS; k < NC; ++k) out2 += 2.0 * (re[k] * re[k] + im[k] * im[k]);
+        for (int k = 0; k < N; ++k) all2 += re[k] * re[k] + im[k] * im[k];
+        const double hout = sqrt(out2 / N) * (1.0 + 1e-9);
+        ecoef[q] = (float)(((double)GF3_SCR_GAMMA * Hinf[q] + hout) * (1.0 + 1e-6));
+        hout_sum += hout; hall_sum += sqrt(all2 / N);
     }
+    // (selective only when the chirp lives below the cut: the reference's 0-8 kHz sweep at 48 kHz drops ~1.3 %)
+    sp.ring = Q <= GF3_SCR_RQ && hout_sum <= 0.05 * hall_sum;
+    if (const char* e = getenv("GF3_SCR_R")) sp.R_forced = atoi(e);       // (tuning aid: output blocks per workgroup)
     std::vector<float> tw(2 * NC), twn(2 * (NC / 2 + 1));
     const long double PI2 = 6.283185307179586476925286766559005768L;
     for (int m = 0; m < NC; ++m) { const long double a = -PI2 * m / NC; tw[2 * m] = (float)cosl(a); tw[2 * m + 1] = (float)sinl(a); }
@@ -1524,6 +1546,8 @@ static int build_screen_plan(gf3_ctx* c) {
     HIPCHK(c, upload((float**)&sp.d_Hs, Hs.data(), Hs.size()));
     HIPCHK(c, upload(&sp.d_H0N, H0N.data(), H0N.size()));
     HIPCHK(c, upload(&sp.d_Hinf, Hinf.data(), Hinf.size()));
+    HIPCHK(c, upload((float**)&sp.d_Hb, Hb.data(), Hb.size()));
+    HIPCHK(c, upload(&sp.d_ecoef, ecoef.data(), ecoef.size()));
     sp.ok = true;
     return GF3_OK;
 }
@@ -1548,6 +1572,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     c->cfg = *cfg;
     c->err[0] = 0;
     if (hipGetDevice(&c->device) != hipSuccess) { delete c; return fail(nullptr, GF3_EHIP, "hipGetDevice failed: no usable GPU"); }
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || c->n_cu < 1) c->n_cu = 256;
     c->NC = N / 2; c->K = N / 2 - 1; c->S = N + cfg->CP;
     c->Lc = cfg->Lc > 0 ? cfg->Lc : 5 * c->S;
     const int K = c->K;
@@ -1730,7 +1755,7 @@ extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
     DeviceGuard dg(c);
     void* ptrs[] = {c->d_tw_x[0], c->d_twn_x[0], c->d_tw_x[1], c->d_twn_x[1], c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
                     c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_known_time,
-                    c->scr.d_tw, c->scr.d_twn, c->scr.d_Hs, c->scr.d_H0N, c->scr.d_Hinf};
+                    c->scr.d_tw, c->scr.d_twn, c->scr.d_Hs, c->scr.d_H0N, c->scr.d_Hinf, c->scr.d_Hb, c->scr.d_ecoef};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete c;
 }
@@ -2054,6 +2079,30 @@ extern "C" int64_t gf3_sync_stream_workspace_bytes(const gf3_ctx* c, int64_t n) 
     return (int64_t)stream_ws(c, n).total;
 }
 
+// The screening pass: the band-limited ring kernel when the plan allows it (and `general` is not asked for), else
+// the general kernel.  R, the ring kernel's blocks per workgroup: every workgroup transforms Q - 1 windows without
+// finishing a block, so R is as large as leaves a whole number of rounds of 2 workgroups per CU (config-3 stream,
+// 83 582 blocks: R = 164 -> 510 workgroups 1.71 ms, R = 82 1.72, R = 32 2.0, and 2.2 at R = 110 = 1.5 rounds).
+static hipError_t launch_screen(const gf3_ctx* c, ScreenArgs a, bool general, hipStream_t st) {
+    const auto& sp = c->scr;
+    hipError_t e = hipSuccess;
+    if (sp.ring && !general) {
+        const int64_t slots = 2 * (int64_t)c->n_cu;                                       // workgroups resident at once
+        const int64_t rounds = (a.nblk + slots * 170 - 1) / (slots * 170);
+        int64_t R = sp.R_forced > 0 ? sp.R_forced : (a.nblk + slots * rounds - 1) / (slots * rounds);
+        if (R < 4) R = 4;
+        a.Hb = sp.d_Hb; a.ecoef = sp.d_ecoef; a.R = (int)R;
+        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (64 + 4 + 2 + 2) * sizeof(float);
+        const int64_t grid = (((a.nblk + R - 1) / R + 7) / 8) * 8;                        // padded to the 8 XCDs (xcd_order)
+        DISPATCH_DT(a.dt, e = launch((scr_ring_kernel<DTC>), grid, GF3_SCR_T, lds, st, a));
+    } else {
+        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 5 * GF3_SCR_B + 4) * sizeof(float);
+        const int64_t grid = (((a.nblk + GF3_SCR_B - 1) / GF3_SCR_B + 7) / 8) * 8;
+        DISPATCH_DT(a.dt, e = launch((scr_ols_kernel<DTC>), grid, GF3_SCR_T, lds, st, a));
+    }
+    return e;
+}
+
 // Screened path of gf3_sync_stream (gf3rx_screen.h).  Enqueues everything on `st`; the caller reads back
 // {peaks, suppression status} at np and the ScrMisc block.  d_dbg (tests): fp64 values of the candidate cells.
 static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const StreamWs& w, char* base, int64_t* d_peaks,
@@ -2079,12 +2128,8 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
         int* run_lo = (int*)(base + w.o_smisc + sizeof(ScrMisc));       // running lower bound of the maximum (float bits; 0 = none yet)
         HIPCHK(c, hipMemsetAsync(run_lo, 0, sizeof(int), st));
         ScreenArgs a{d_r, n, dt, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, w.s_nblk, w.plen,
-                     P32, blk_max, blk_err, run_lo, (float)c->cfg.thresh};
-        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 5 * GF3_SCR_B + 4) * sizeof(float);
-        const int64_t grid = (((w.s_nblk + GF3_SCR_B - 1) / GF3_SCR_B + 7) / 8) * 8;      // padded to the 8 XCDs (scr_ols_kernel's block order)
-        hipError_t e = hipSuccess;
-        DISPATCH_DT(dt, e = launch((scr_ols_kernel<DTC>), grid, GF3_SCR_T, lds, st, a));
-        HIPCHK(c, e);
+                     P32, blk_max, blk_err, run_lo, (float)c->cfg.thresh, nullptr, nullptr, 0};
+        HIPCHK(c, launch_screen(c, a, c->stream_mode == 3, st));
     }
     hipLaunchKernelGGL(scr_mlo_kernel, dim3(1), dim3(1024), 0, st, (const float*)blk_max, (const float*)blk_err, w.s_nblk, misc);
     auto list_cells = [&](int which, int64_t* cells, int64_t capc) {
@@ -2125,7 +2170,8 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
 // (3 M-sample recording: 0.24 ms screened, 0.15 ms all-fp64; 321 M samples: 3.8 vs 7.2 ms; the lines cross near 7 M).
 #define GF3_SCR_MIN_SAMPLES ((int64_t)1 << 23)
 extern "C" int gf3_sync_stream_mode(gf3_ctx* c, int32_t mode) {
-    if (!c || mode < 0 || mode > 2) return fail(c, GF3_EINVAL, "gf3_sync_stream_mode: mode must be 0 (by length), 1 (fp64 only) or 2 (always screen)");
+    if (!c || mode < 0 || mode > 3)
+        return fail(c, GF3_EINVAL, "gf3_sync_stream_mode: mode must be 0 (by length), 1 (fp64 only), 2 (always screen) or 3 (always screen, general kernel)");
     c->stream_mode = mode;
     return GF3_OK;
 }
@@ -2144,11 +2190,8 @@ extern "C" int gf3_debug_stream_screen(gf3_ctx* c, const void* d_r, int64_t n, f
     const int64_t plen = n + c->Lc - 1, nblk = (plen + sp.H - 1) / sp.H;
     *h_hop = sp.H;
     ScreenArgs a{d_r, n, c->cfg.in_dtype, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, nblk, plen,
-                 d_p32, d_blk, d_blk + nblk, nullptr, 0.0f};                 // (no skipping: the tests look at every lag)
-    const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 5 * GF3_SCR_B + 4) * sizeof(float);
-    hipError_t e = hipSuccess;
-    DISPATCH_DT(a.dt, e = launch((scr_ols_kernel<DTC>), (((nblk + GF3_SCR_B - 1) / GF3_SCR_B + 7) / 8) * 8, GF3_SCR_T, lds, (hipStream_t)stream, a));
-    HIPCHK(c, e);
+                 d_p32, d_blk, d_blk + nblk, nullptr, 0.0f, nullptr, nullptr, 0};      // (no skipping: the tests look at every lag)
+    HIPCHK(c, launch_screen(c, a, c->stream_mode == 3, (hipStream_t)stream));
     return GF3_OK;
 }
 
@@ -2170,7 +2213,7 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     int64_t* np = (int64_t*)(base + w.o_misc + 16);        // [count, status]
     const CorrPlan& pl = c->stream_plan;
     c->last_info[0] = 2; c->last_info[1] = c->last_info[2] = c->last_info[3] = 0;
-    if (!d_corr && c->scr.ok && w.s_nblk > 0 && (c->stream_mode == 2 || (c->stream_mode == 0 && n >= GF3_SCR_MIN_SAMPLES))) {
+    if (!d_corr && c->scr.ok && w.s_nblk > 0 && (c->stream_mode >= 2 || (c->stream_mode == 0 && n >= GF3_SCR_MIN_SAMPLES))) {
         int rc = sync_stream_screened(c, d_r, n, w, base, d_peaks, cap, nullptr, st);
         if (rc != GF3_OK) return rc;
         int64_t h[2] = {0, 0};

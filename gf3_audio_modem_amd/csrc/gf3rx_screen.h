@@ -121,13 +121,19 @@ struct ScreenArgs {
     float* blk_err;            // [nblk] bound on |P32 - P| for every lag of the block
     int* run_lo;               // optional: running lower bound of the maximum (float bits, > 0), shared by the grid
     float thresh;              // 0 < thresh < 1 enables skipping the store of blocks that cannot matter
+    // band-limited kernel (scr_ring_kernel) only:
+    const float4* Hb;          // [Q][GF3_SCR_KS / 2][256]: (H_q[k], H_q[k + 256]), k = t + 512 p  -- the bins below 256 GF3_SCR_KS
+    const float* ecoef;        // [Q] error per unit |x|_2: rounding (GF3_SCR_GAMMA max|H_q|) + the dropped bins' |h_q,out|_2
+    int R;                     // output blocks per workgroup
 };
 
 // one window: samples -> spectrum slots.  X[2r] = X[k_r], X[2r+1] = X[4096 - k_r], k_r = t + 256 r (thread 0, r = 0:
 // both slots hold bin 2048); thread 0 also gets DC and Nyquist in z0 = (X[0], X[4096]).  Returns this thread's
 // share of the window's energy (sum of squares of the 32 samples it loaded).
+// (first part, shared with the band-limited kernel: samples -> complex transform, left in natural order in P; the
+//  caller puts a barrier between this and its reads of P)
 template <int DT>
-GF3_DEV float scr_window_spectrum(const ScreenArgs& a, int64_t seg, cf (&v)[16], cf& z0, cf* P, cf* Q, cf tw2, cf tw3, cf wb, int t) {
+GF3_DEV float scr_window_fft(const ScreenArgs& a, int64_t seg, cf (&v)[16], cf* P, cf* Q, cf tw2, cf tw3, int t) {
     typedef typename RawT<DT>::E E;
     // valid part of the window in window-relative sample numbers [lo, hi): 32-bit per-lane arithmetic from here on
     const int lo = seg >= 0 ? 0 : (seg <= -(int64_t)(2 * GF3_SCR_NC) ? 2 * GF3_SCR_NC : (int)(-seg));
@@ -159,6 +165,11 @@ GF3_DEV float scr_window_spectrum(const ScreenArgs& a, int64_t seg, cf (&v)[16],
     // exchange for the packed-real split: natural order into P (free: every thread is past the second barrier)
 #pragma unroll
     for (int m = 0; m < 16; ++m) P[t + 256 * m] = v[scr_perm(m)];
+    return e2;
+}
+template <int DT>
+GF3_DEV float scr_window_spectrum(const ScreenArgs& a, int64_t seg, cf (&v)[16], cf& z0, cf* P, cf* Q, cf tw2, cf tw3, cf wb, int t) {
+    const float e2 = scr_window_fft<DT>(a, seg, v, P, Q, tw2, tw3, t);
     lds_barrier();
     z0 = P[0];
     const float c32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
@@ -325,6 +336,169 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
                 if (a.run_lo && lo > 0.0f && lo > run) atomicMax(a.run_lo, __float_as_int(lo));   // positive floats order like their bits; rare once a chirp has been seen
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------- band-limited screening kernel
+// The reference's chirp sweeps 0 .. 8 kHz at fs = 48 kHz (OFDM.py:106-109): above bin 8192 * 8000 / 48000 = 1365 of an
+// 8192-sample window the partitions' spectra hold about 1 % of their energy (the tails of the segment edges).
+// Leaving the bins |k| >= 256 KS = 1536 out of the products changes a lag of one (window, partition) term by at most
+//     |y_drop|_inf <= (1/N) sum_dropped |X[k]| |H_q[k]| <= |x|_2 |h_q,out|_2,   |h_q,out|_2^2 = (1/N) sum_dropped |H_q[k]|^2
+// (Cauchy-Schwarz, then Parseval for both factors; the host evaluates |h_q,out|_2 in fp64 and rounds up), which joins
+// the rounding term in the block's error bound: nothing else in the method changes, the bound stays rigorous and the
+// decisions stay fp64.  What it buys: a block's accumulator is KS = 6 complex registers per thread instead of 16, so a
+// RING of up to RQ = 8 unfinished blocks fits in registers and a workgroup walks R consecutive blocks with ONE forward
+// transform per window -- 2 + (Q - 1) / R transforms per block where scr_ols_kernel, which has to re-transform the
+// Q + B - 1 windows under its B = 4 blocks, needs 3.25 (Q = 6) -- and 6 instead of 16 multiply-adds per partition.
+// Used when Q <= RQ and the dropped share is small (build_screen_plan); otherwise scr_ols_kernel.
+#define GF3_SCR_KS 6                 /* slots t + 256 r, r < KS, of the half spectrum are kept (even: read in pairs) */
+#define GF3_SCR_RQ 8                 /* ring depth = largest Q */
+template <int DT>
+__global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
+    extern __shared__ double2 smem[];
+    constexpr int NC = GF3_SCR_NC, T = GF3_SCR_T, KS = GF3_SCR_KS, RQ = GF3_SCR_RQ;
+    cf* bufA = (cf*)smem;
+    cf* bufB = bufA + NC;
+    float* nrm = (float*)(bufB + NC);                 // [16][4] energy of window j in row j & 15, per wave
+    float* red = nrm + 64;                            // [4] per-wave maximum of the finished block
+    float* bc = red + 4;                              // [2] the finished block's error bound; the grid's running bound as read for it
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    // (XCD-aware order as in scr_ols_kernel: each XCD walks its own contiguous eighth of the stream)
+    const int64_t b0 = (int64_t)a.R * xcd_order(blockIdx.x, gridDim.x);
+    if (b0 >= a.nblk) return;                                          // (uniform: padding workgroups)
+    const int64_t b1 = b0 + a.R < a.nblk ? b0 + a.R : a.nblk;
+    cf tw2 = a.tw[(t & 15) * 16], tw3 = a.tw[t], wb = a.twn[t];
+    auto refresh = [&]() {                            // (see scr_ols_kernel: keeps the twiddle powers out of the loop-invariant set)
+        asm volatile("" : "+v"(tw2.x), "+v"(tw2.y), "+v"(tw3.x), "+v"(tw3.y), "+v"(wb.x), "+v"(wb.y));
+    };
+    cf acc[RQ][KS];                                   // acc[i]: block j - (Q - 1) + i while window j is being added
+#pragma unroll
+    for (int i = 0; i < RQ; ++i)
+#pragma unroll
+        for (int r = 0; r < KS; ++r) acc[i][r] = cfmk(0.0f, 0.0f);
+    const float inv = 0.25f / (float)NC;              // 1/NC of the inverse transform, 1/2 of each of the two splits
+    const float c32[8] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                          0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+    const float s32[8] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                          0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f};
+    const bool may_skip = a.run_lo != nullptr && a.thresh > 0.0f && a.thresh < 1.0f;
+    const float ec = lane < a.Q ? a.ecoef[lane] : 0.0f;   // this lane's coefficient of the error bound (wave 0 sums lanes 0 .. Q - 1)
+    for (int64_t j = b0; j < b1 + (a.Q - 1); ++j) {    // windows: block b is the sum over h of window b + h with partition h
+        cf v[16];
+        const int64_t seg = j * (int64_t)a.H - (a.Lc - 1);
+        refresh();
+        float e2 = scr_window_fft<DT>(a, seg, v, bufA, bufB, tw2, tw3, t);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) e2 += __shfl_xor(e2, d, 64);
+        if (lane == 0) nrm[(int)(j & 15) * 4 + wave] = e2;
+        lds_barrier();
+        // packed-real split, kept bins only: X[r] = 2 X[t + 256 r]  (k = 0 pairs with itself: its slot is 2 X[0], real)
+        cf X[KS];
+#pragma unroll
+        for (int r = 0; r < KS; ++r) {
+            const int k = t + 256 * r;
+            const cf A = bufA[k], Bc = cfconj(bufA[(NC - k) & (NC - 1)]);
+            const cf w = cfmul(wb, cfmk(c32[r], -s32[r]));                // exp(-2 pi i k / 8192)
+            const cf Ee = cfadd(A, Bc), Dd = cfsub(A, Bc);
+            X[r] = cfadd(Ee, cfmul(cf_negi(Dd), w));
+        }
+#pragma unroll
+        for (int i = 0; i < RQ; ++i) {
+            int h = a.Q - 1 - i;                       // ring slot i holds block j - h
+            asm volatile("" : "+s"(h));                // (kept scalar and out of the loop-invariant set: hoisted, the eight partitions'
+                                                       //  per-lane 64-bit addresses are spilled around the transforms)
+            if (h >= 0) {                              // (uniform)
+                const float4* Hp = a.Hb + (int64_t)h * (KS / 2) * T;
+#pragma unroll
+                for (int p = 0; p < KS / 2; ++p) {
+                    const float4 hh = Hp[(unsigned)(p * T + t)];
+                    acc[i][2 * p] = cf_fma_conj(X[2 * p], cfmk(hh.x, hh.y), acc[i][2 * p]);
+                    acc[i][2 * p + 1] = cf_fma_conj(X[2 * p + 1], cfmk(hh.z, hh.w), acc[i][2 * p + 1]);
+                }
+                asm volatile("" ::: "memory");        // one partition's loads in flight at a time
+            }
+        }
+        const int64_t b = j - (a.Q - 1);               // the block this window completes
+        if (b >= b0) {                                 // (uniform; the first Q - 1 windows only fill the ring)
+            // ---- inverse real FFT of the Hermitian spectrum whose kept half is acc[0]; every other bin is zero
+            refresh();
+#pragma unroll
+            for (int r = 0; r < KS; ++r) {
+                const int k = t + 256 * r;
+                const bool dc = (r == 0 && t == 0);
+                const cf w = cfmul(wb, cfmk(c32[r], -s32[r]));
+                const cf A = acc[0][r];
+                const cf Op = cfmul(A, cfconj(w));                          // * exp(+2 pi i k / 8192)
+                const cf Zk = cfadd(A, cf_posi(Op));
+                const cf Zm = cfadd(cfconj(A), cf_posi(cfconj(Op)));
+                bufB[k] = cfconj(Zk);
+                // (bin 4096 - k; k = 0 has no partner, and thread 0 uses the turn to clear the one bin of the dropped
+                //  range [1536, 2560] that is read from LDS below rather than known to be zero)
+                bufB[dc ? 2560 : NC - k] = dc ? cfmk(0.0f, 0.0f) : cfconj(Zm);
+            }
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = (r >= KS && r < 16 - KS) ? cfmk(0.0f, 0.0f) : bufB[t + 256 * r];
+            scr_fft4096(v, bufA, bufB, tw2, tw3, t);
+            // z = conj(FFT(conj Z)) / NC ; y[2n] = Re z, y[2n+1] = Im z, n = t + 256 m; the block's lags are n < H / 2 <= 2048
+            const int64_t m0 = b * (int64_t)a.H;
+            const int64_t left = a.plen - m0;
+            const int W = left < a.H ? (int)left : a.H;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int i = 2 * (t + 256 * m);
+                const cf z = v[scr_perm(m)];
+                const float y0 = z.x * inv, y1 = -z.y * inv;
+                if (i + 1 < W) mx = fmaxf(mx, fmaxf(y0, y1));
+                else if (i < W) mx = fmaxf(mx, y0);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            if (lane == 0) red[wave] = mx;
+            if (wave == 0) {                           // error bound of block b: windows b .. b + Q - 1, one per lane
+                const float* n4 = nrm + (int)((b + lane) & 15) * 4;
+                // (lanes from Q on look at rows that may never have been written: their term is dropped, not multiplied by 0)
+                float e = lane < a.Q ? ec * (sqrtf((n4[0] + n4[1]) + (n4[2] + n4[3])) * 1.0001f) : 0.0f;
+#pragma unroll
+                for (int d = 8; d >= 1; d >>= 1) e += __shfl_xor(e, d, 64);
+                if (lane == 0) {
+                    bc[0] = e * 1.0001f + 1e-37f;
+                    // (one lane reads the shared bound -- 256 lanes hammering one address would serialise the whole grid)
+                    bc[1] = may_skip ? __int_as_float(__atomic_load_n(a.run_lo, __ATOMIC_RELAXED)) : 0.0f;
+                }
+            }
+            lds_barrier();
+            const float bmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const float be = bc[0], run = bc[1];
+            // (same rule as scr_ols_kernel: a block whose upper bound stays below thresh x an established lower bound
+            //  of the maximum can hold neither the maximum nor a candidate; its lags are never read again)
+            const bool skip = may_skip && run > 0.0f && (bmax + be) < a.thresh * run * (1.0f - 1e-6f) * 0.9999f;
+            if (!skip) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int i = 2 * (t + 256 * m);
+                    const cf z = v[scr_perm(m)];
+                    const float y0 = z.x * inv, y1 = -z.y * inv;
+                    if (i + 1 < W) *(float2*)(a.P32 + m0 + i) = make_float2(y0, y1);
+                    else if (i < W) a.P32[m0 + i] = y0;
+                }
+            }
+            if (t == 0) {
+                a.blk_max[b] = bmax;
+                a.blk_err[b] = be;
+                const float lo = bmax - be;
+                if (a.run_lo && lo > 0.0f && lo > run) atomicMax(a.run_lo, __float_as_int(lo));
+            }
+        } else {
+            lds_barrier();                             // (the next window's first stores go to bufA, which the split above reads)
+        }
+#pragma unroll
+        for (int i = 0; i + 1 < RQ; ++i)
+#pragma unroll
+            for (int r = 0; r < KS; ++r) acc[i][r] = acc[i + 1][r];
+#pragma unroll
+        for (int r = 0; r < KS; ++r) acc[RQ - 1][r] = cfmk(0.0f, 0.0f);
     }
 }
 

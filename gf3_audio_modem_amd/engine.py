@@ -269,8 +269,9 @@ class Engine:
 
     def sync_stream_mode(self, mode):
         """gf3_sync_stream_mode: 0 (default) fp32 screening + fp64 decisions from 2^23 samples on, all-fp64 below;
-        1 always the all-fp64 overlap-save path; 2 screened at any length.  (A screen that is not selective, and any
-        call that asks for P, takes the all-fp64 path regardless.)"""
+        1 always the all-fp64 overlap-save path; 2 screened at any length; 3 as 2 with the general screening kernel
+        where the band-limited one would run.  (A screen that is not selective, and any call that asks for P, takes
+        the all-fp64 path regardless.)"""
         self._check(self.lib.gf3_sync_stream_mode(self._h, int(mode)))
 
     def sync_stream_info(self):

@@ -169,7 +169,10 @@ int gf3_sync_stream(gf3_ctx *ctx, const void *d_r, int64_t n,
  * products, and the reference's rule (global maximum, threshold, extremum test) is applied to those fp64 values -- no
  * decision rests on an fp32 number; streams on which the screen is not selective take the all-fp64 overlap-save.
  * mode 0 (default): screened for streams of 2^23 samples or more (below that the all-fp64 path is the faster one);
- * mode 1: always all-fp64; mode 2: screened at any length.  Calls that ask for d_corr are always all-fp64.
+ * mode 1: always all-fp64; mode 2: screened at any length; mode 3: as 2, with the general screening kernel even
+ * where the band-limited one applies (a chirp whose spectrum lives below 3/16 of the sample rate, as the reference's
+ * 0-8 kHz sweep at 48 kHz does: the bins above are left out of the fp32 products and their norm joins the error
+ * bound).  Calls that ask for d_corr are always all-fp64.
  * The mode and the info block below are plain fields of the context: set / read them from the thread that calls
  * gf3_sync_stream on that context.
  */
