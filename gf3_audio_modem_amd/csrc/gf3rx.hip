@@ -1328,7 +1328,7 @@ struct gf3_ctx {
              float *d_H0N = nullptr, *d_Hinf = nullptr;
              bool ring = false; float4* d_Hb = nullptr; float* d_ecoef = nullptr; int R_forced = 0; } scr;   // band-limited kernel (scr_ring_kernel)
     int stream_mode = 0;                // 0: by stream length (screen from GF3_SCR_MIN_SAMPLES on); 1: fp64 only; 2: screen whenever a plan exists; 3: as 2 with the general kernel
-    int64_t last_info[4] = {0, 0, 0, 0};   // last gf3_sync_stream: path taken (0 screened, 1 fp64 after fallback, 2 fp64), cells A, cells B, candidates
+    int64_t last_info[4] = {0, 0, 0, 0};   // last gf3_sync_stream: path taken (0 screened, 1 fp64 after fallback, 2 fp64), cells re-evaluated, cells holding a candidate, candidates
     std::vector<double> chirp;
     std::vector<cplx> known_pts;
     mutable char err[512];
@@ -2030,8 +2030,8 @@ extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64
 // workspace layout for gf3_sync_stream
 struct StreamWs { int64_t plen, nz, nb_max, nb_c, nblk, nwin; size_t o_P, o_part, o_cnt, o_off, o_cand, o_misc, o_spec, total;
                   // screened path (gf3rx_screen.h); P32 overlays o_P, the per-workgroup counts / offsets overlay o_cnt / o_off
-                  int64_t s_nblk, s_ncell, s_nwg, s_capA, s_capB;
-                  size_t o_sblk, o_smisc, o_cellA, o_cmaxA, o_cellB, o_maskB, o_cntB, o_offB; };
+                  int64_t s_nblk, s_ncell, s_nwg, s_cap;
+                  size_t o_sblk, o_smisc, o_cell, o_cmax, o_cval, o_mask, o_ccnt, o_coff; };
 static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
     StreamWs w;
     w.plen = n + c->Lc - 1; w.nz = w.plen - 2;
@@ -2051,22 +2051,23 @@ static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
     w.nblk = (w.plen + c->stream_plan.Lp - 1) / c->stream_plan.Lp;
     w.nwin = w.nblk + c->stream_plan.Q - 1;
     w.o_spec = take((size_t)w.nwin * (c->stream_plan.NC + 1) * sizeof(cplx));
-    w.s_nblk = w.s_ncell = w.s_nwg = w.s_capA = w.s_capB = 0;
+    w.s_nblk = w.s_ncell = w.s_nwg = w.s_cap = 0;
     if (c->scr.ok) {
         w.s_nblk = (w.plen + c->scr.H - 1) / c->scr.H;
         w.s_ncell = (w.nz + GF3_SCR_CELL - 1) / GF3_SCR_CELL;
         if (w.s_ncell < 1) w.s_ncell = 1;
         w.s_nwg = (w.s_ncell + SCR_LIST_THREADS * SCR_LIST_GROUPS - 1) / (SCR_LIST_THREADS * SCR_LIST_GROUPS);
-        w.s_capA = 4096 + 4 * (n / (c->Lc > 0 ? c->Lc : 1) + 1);   // every chirp of a clean stream peaks within the bound of the maximum
-        w.s_capB = w.s_ncell / 16 > 4096 ? w.s_ncell / 16 : 4096;
+        // work list: a sixteenth of all cells (a clean stream lists two or three cells per chirp, one chirp per > 5 Lc
+        // samples = 25 cells at the very least), never fewer than 4096
+        w.s_cap = w.s_ncell / 16 > 4096 ? w.s_ncell / 16 : 4096;
         w.o_sblk = take((size_t)w.s_nblk * 8);                 // blk_max | blk_err (float each)
         w.o_smisc = take(sizeof(ScrMisc) + 16);                // (+ the screen's running lower bound of the maximum)
-        w.o_cellA = take((size_t)w.s_capA * 8);
-        w.o_cmaxA = take((size_t)w.s_capA * 8);
-        w.o_cellB = take((size_t)w.s_capB * 8);
-        w.o_maskB = take((size_t)w.s_capB * 4);
-        w.o_cntB = take((size_t)w.s_capB * 8);
-        w.o_offB = take((size_t)w.s_capB * 8);
+        w.o_cell = take((size_t)w.s_cap * 8);
+        w.o_cmax = take((size_t)w.s_cap * 8);
+        w.o_cval = take((size_t)w.s_cap * 16 * 8);
+        w.o_mask = take((size_t)w.s_cap * 4);
+        w.o_ccnt = take((size_t)w.s_cap * 8);
+        w.o_coff = take((size_t)w.s_cap * 8);
         if ((size_t)w.s_nwg > (size_t)w.nb_c) {                // (cannot happen: 3584 lags per list workgroup vs 2048 per candidate block)
             w.s_nblk = 0;
         }
@@ -2104,9 +2105,9 @@ static hipError_t launch_screen(const gf3_ctx* c, ScreenArgs a, bool general, hi
 }
 
 // Screened path of gf3_sync_stream (gf3rx_screen.h).  Enqueues everything on `st`; the caller reads back
-// {peaks, suppression status} at np and the ScrMisc block.  d_dbg (tests): fp64 values of the candidate cells.
+// {peaks, suppression status} at np and the ScrMisc block.
 static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const StreamWs& w, char* base, int64_t* d_peaks,
-                                int64_t cap, double* d_dbg, hipStream_t st) {
+                                int64_t cap, hipStream_t st) {
     const auto& sp = c->scr;
     float* P32 = (float*)(base + w.o_P);
     float* blk_max = (float*)(base + w.o_sblk);
@@ -2117,48 +2118,42 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
     int64_t* total = (int64_t*)(base + w.o_misc + 8);
     int64_t* np = (int64_t*)(base + w.o_misc + 16);
     int64_t* cand = (int64_t*)(base + w.o_cand);
-    int64_t* cellA = (int64_t*)(base + w.o_cellA);
-    double* cmaxA = (double*)(base + w.o_cmaxA);
-    int64_t* cellB = (int64_t*)(base + w.o_cellB);
-    unsigned* maskB = (unsigned*)(base + w.o_maskB);
-    int64_t* cntB = (int64_t*)(base + w.o_cntB);
-    int64_t* offB = (int64_t*)(base + w.o_offB);
+    int64_t* cell = (int64_t*)(base + w.o_cell);
+    double* cmax = (double*)(base + w.o_cmax);
+    double* cval = (double*)(base + w.o_cval);
+    unsigned* mask = (unsigned*)(base + w.o_mask);
+    int64_t* ccnt = (int64_t*)(base + w.o_ccnt);
+    int64_t* coff = (int64_t*)(base + w.o_coff);
     const int dt = c->cfg.in_dtype;
-    {
+    {   // 1. every lag in fp32, with a bound per block
         int* run_lo = (int*)(base + w.o_smisc + sizeof(ScrMisc));       // running lower bound of the maximum (float bits; 0 = none yet)
         HIPCHK(c, hipMemsetAsync(run_lo, 0, sizeof(int), st));
         ScreenArgs a{d_r, n, dt, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, w.s_nblk, w.plen,
                      P32, blk_max, blk_err, run_lo, (float)c->cfg.thresh, nullptr, nullptr, 0};
         HIPCHK(c, launch_screen(c, a, c->stream_mode == 3, st));
     }
-    hipLaunchKernelGGL(scr_mlo_kernel, dim3(1), dim3(1024), 0, st, (const float*)blk_max, (const float*)blk_err, w.s_nblk, misc);
-    auto list_cells = [&](int which, int64_t* cells, int64_t capc) {
-        hipLaunchKernelGGL(scr_cells_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
-                           (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, which, cnt, (const int64_t*)nullptr,
-                           (int64_t*)nullptr, (int64_t)0);
-        hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.s_nwg, offs, total, (const long long*)nullptr);
-        hipLaunchKernelGGL(scr_total_kernel, dim3(1), dim3(1), 0, st, (const int64_t*)total, capc, misc, which);
-        hipLaunchKernelGGL(scr_cells_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
-                           (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, which, cnt, (const int64_t*)offs,
-                           cells, capc);
-    };
-    auto refine = [&](int which, const int64_t* cells, int64_t capc) -> hipError_t {
-        RefineArgs a{d_r, n, dt, c->d_chirp, c->Lc, cells, misc, which, w.plen, w.nz, c->cfg.thresh, cmaxA, maskB, cntB,
-                     which == 1 ? d_dbg : nullptr};
-        hipError_t e = hipSuccess;
-        // fixed grid (the list length lives on the device): workgroups stride over the listed cells
-        const unsigned grid = (unsigned)(capc < 2048 ? capc : 2048);
-        DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine_kernel<DTC>), dim3(grid), dim3(SCR_REF_THREADS), 0, st, a); e = hipGetLastError());
-        return e;
-    };
-    list_cells(0, cellA, w.s_capA);
-    HIPCHK(c, refine(0, cellA, w.s_capA));
-    hipLaunchKernelGGL(scr_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)cmaxA, misc, c->cfg.thresh);
-    list_cells(1, cellB, w.s_capB);
-    HIPCHK(c, refine(1, cellB, w.s_capB));
-    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cntB, w.s_capB, offB, total, (const long long*)&misc->ncellB);
-    hipLaunchKernelGGL(scr_expand_kernel, dim3((unsigned)((w.s_capB + 255) / 256)), dim3(256), 0, st, (const int64_t*)cellB, (const unsigned*)maskB,
-                       (const int64_t*)offB, (const ScrMisc*)misc, cand, w.nz + 2);
+    // 2. the cells whose lags the bounds cannot exclude, in ascending order (count, scan, write)
+    hipLaunchKernelGGL(scr_mlo_kernel, dim3(1), dim3(1024), 0, st, (const float*)blk_max, (const float*)blk_err, w.s_nblk, misc, c->cfg.thresh);
+    hipLaunchKernelGGL(scr_cells_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
+                       (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, cnt, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0);
+    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.s_nwg, offs, total, (const long long*)nullptr);
+    hipLaunchKernelGGL(scr_total_kernel, dim3(1), dim3(1), 0, st, (const int64_t*)total, w.s_cap, misc);
+    hipLaunchKernelGGL(scr_cells_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
+                       (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, cnt, (const int64_t*)offs, cell, w.s_cap);
+    {   // 3. their lags in fp64, once; the maximum; the reference's rule on those values
+        RefineArgs a{d_r, n, dt, c->d_chirp, c->Lc, cell, misc, w.plen, cval, cmax};
+        const int64_t slots = 2 * (int64_t)c->n_cu;                         // (the LDS staging allows two workgroups per CU)
+        const unsigned grid = (unsigned)(w.s_cap < slots ? w.s_cap : slots);
+        DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine_kernel<DTC>), dim3(grid), dim3(SCR_REF_THREADS), 0, st, a));
+        HIPCHK(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(scr_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)cmax, misc);
+    hipLaunchKernelGGL(scr_decide_kernel, dim3((unsigned)((w.s_cap + 255) / 256)), dim3(256), 0, st, (const int64_t*)cell, (const double*)cval, misc,
+                       w.nz, (double)c->cfg.thresh, mask, ccnt);
+    // 4. candidates in ascending order, suppression walk
+    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)ccnt, w.s_cap, coff, total, (const long long*)&misc->ncell);
+    hipLaunchKernelGGL(scr_expand_kernel, dim3((unsigned)((w.s_cap + 255) / 256)), dim3(256), 0, st, (const int64_t*)cell, (const unsigned*)mask,
+                       (const int64_t*)coff, (const ScrMisc*)misc, cand, w.nz + 2);
     hipLaunchKernelGGL(scr_guard_kernel, dim3(1), dim3(1), 0, st, (const ScrMisc*)misc, total);
     hipLaunchKernelGGL(pk_nms, dim3(1), dim3(NMS_THREADS), 0, st, (const int64_t*)cand, (const int64_t*)total,
                        (int64_t)c->Lc, w.nz, d_peaks, cap, np);
@@ -2214,7 +2209,7 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     const CorrPlan& pl = c->stream_plan;
     c->last_info[0] = 2; c->last_info[1] = c->last_info[2] = c->last_info[3] = 0;
     if (!d_corr && c->scr.ok && w.s_nblk > 0 && (c->stream_mode >= 2 || (c->stream_mode == 0 && n >= GF3_SCR_MIN_SAMPLES))) {
-        int rc = sync_stream_screened(c, d_r, n, w, base, d_peaks, cap, nullptr, st);
+        int rc = sync_stream_screened(c, d_r, n, w, base, d_peaks, cap, st);
         if (rc != GF3_OK) return rc;
         int64_t h[2] = {0, 0};
         ScrMisc hm;
@@ -2223,7 +2218,7 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
         int64_t ncand = 0;
         HIPCHK(c, hipMemcpyAsync(&ncand, total, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
-        c->last_info[1] = hm.ncellA; c->last_info[2] = hm.ncellB; c->last_info[3] = ncand;
+        c->last_info[1] = hm.ncell; c->last_info[2] = hm.nhit; c->last_info[3] = ncand;
         if (!(hm.status & 1)) {
             c->last_info[0] = 0;
             *n_peaks = h[0];

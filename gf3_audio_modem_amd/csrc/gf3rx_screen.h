@@ -4,11 +4,13 @@
 //   (1) its global maximum M, (2) the lags i with P[i+1]/M > thresh that are local extrema, (3) the suppression walk.
 // Only a handful of lags around every chirp ever pass (2).  So P is first evaluated in fp32 for EVERY lag (uniformly
 // partitioned overlap-save, forward transforms fused into the accumulation: no spectra in HBM), together with a bound
-// E_b on |P32 - P| for each output block; then
-//   * every lag whose upper bound P32 + E_b reaches the best lower bound  max(P32 - E_b)  could be the maximum:
-//     those lags are re-evaluated as fp64 dot products with the fp64 replica, and M is the largest of them;
-//   * every lag whose upper bound exceeds  thresh M (1 - 1e-6)  could pass (2): those lags and their two
-//     neighbours are re-evaluated in fp64 and the reference's rule is applied literally to the fp64 values.
+// E_b on |P32 - P| for each output block.  With Mlo = max(P32 - E_b) <= M:
+//   * a lag that could be the maximum has an upper bound P32 + E_b >= Mlo;
+//   * a lag that could pass (2) has an upper bound >= thresh M (1 - 1e-6) >= thresh Mlo (1 - 1e-6).
+// So every lag that matters has an upper bound >= min(Mlo, thresh Mlo (1 - 1e-6)), a level known before any fp64 value
+// is.  The lags above it (in cells of 14, with the two neighbours the extremum test needs) are re-evaluated ONCE as fp64
+// dot products with the fp64 replica; M is the largest of those values and the reference's rule is applied literally to
+// the same values.
 // No decision is ever taken on an fp32 value: fp32 only proves, with a margin, which lags need NOT be looked at.
 // If the screen is not selective (constant streams, pathological thresholds: more cells than the work list holds)
 // the caller falls back to the all-fp64 path (spec_kernel + ols_kernel), which is also what serves `d_corr`.
@@ -506,17 +508,29 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
 struct ScrMisc {                  // device-resident scalars of one gf3_sync_stream call
     double Mlo;                   // best lower bound of the maximum: max_b (blk_max - blk_err)
     double M;                     // the maximum (fp64 re-evaluation)
-    double lim;                   // lags whose upper bound stays below this cannot pass the threshold
-    long long ncellA, ncellB;     // cells listed for the maximum / for the candidates
-    long long status;             // bit 0: a work list overflowed -> the caller falls back to the all-fp64 path
+    double lim;                   // listing level: a lag whose upper bound stays below it can neither be the maximum nor pass the threshold
+    long long ncell;              // cells listed (and re-evaluated)
+    long long nhit;               // of those, cells that hold a candidate
+    long long status;             // bit 0: the work list overflowed -> the caller falls back to the all-fp64 path
+    long long next;               // work counter of scr_refine_kernel
 };
 
-__global__ void scr_mlo_kernel(const float* blk_max, const float* blk_err, int64_t nblk, ScrMisc* misc) {
+// One list serves both questions.  With Mlo <= M:  a lag that could be the maximum has an upper bound >= Mlo, a lag
+// that could pass the threshold has one >= thresh M (1 - 1e-6) >= thresh Mlo (1 - 1e-6); so every lag that matters has
+// an upper bound >= lim = min(Mlo, thresh Mlo (1 - 1e-6)), known BEFORE any fp64 value is.  The cells under those lags
+// are re-evaluated once; M is the largest of their fp64 values and the rule is then applied to the same values.
+__global__ void scr_mlo_kernel(const float* blk_max, const float* blk_err, int64_t nblk, ScrMisc* misc, double thresh) {
     __shared__ double scratch[16];
     double m = -INFINITY;
     for (int64_t i = threadIdx.x; i < nblk; i += blockDim.x) m = fmax(m, (double)blk_max[i] - (double)blk_err[i]);
     m = block_max(m, scratch);
-    if (threadIdx.x == 0) { misc->Mlo = m; misc->status = 0; misc->ncellA = misc->ncellB = 0; }
+    if (threadIdx.x == 0) {
+        misc->Mlo = m; misc->status = 0; misc->ncell = misc->nhit = 0; misc->next = 0;
+        // (the prefilter of pk_candidates: only a positive finite maximum and threshold exclude anything; a NaN bound
+        //  lists everything, which overflows the list and falls back)
+        const bool filt = m > 0.0 && thresh > 0.0 && m < INFINITY && thresh < INFINITY;
+        misc->lim = filt ? fmin(m, thresh * m * (1.0 - 1e-6)) : (m == m ? -INFINITY : NAN);
+    }
 }
 
 // Cells: cell c = centre lags m = 1 + 14 c .. 14 + 14 c of the full correlation (zeros-indices i = m - 1); its
@@ -527,12 +541,12 @@ __global__ void scr_mlo_kernel(const float* blk_max, const float* blk_err, int64
 #define SCR_LIST_GROUPS 16           /* groups of 256 cells per workgroup: 4096 cells = 57 344 lags */
 __global__ __launch_bounds__(SCR_LIST_THREADS) void scr_cells_kernel(const float* __restrict__ P32, const float* __restrict__ blk_max,
                                                                      const float* __restrict__ blk_err, int H, int64_t plen, int64_t ncell,
-                                                                     const ScrMisc* misc, int which, int64_t* counts,
+                                                                     const ScrMisc* misc, int64_t* counts,
                                                                      const int64_t* offsets, int64_t* cells, int64_t cap) {
     __shared__ int wsum[SCR_LIST_THREADS / 64];
     if (misc->status & 1) { if (!offsets && threadIdx.x == 0) counts[blockIdx.x] = 0; return; }
     if (offsets && counts[blockIdx.x] == 0) return;
-    const double level = which == 0 ? misc->Mlo : misc->lim;
+    const double level = misc->lim;
     const bool all = !(level == level);                                      // NaN level: nothing can be excluded
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Which of the (at most 64) output blocks under this workgroup's lags can reach the level at all: one parallel
@@ -602,10 +616,10 @@ __global__ __launch_bounds__(SCR_LIST_THREADS) void scr_cells_kernel(const float
     if (!offsets && threadIdx.x == 0) counts[blockIdx.x] = run;
 }
 
-// total of a cell list -> misc, overflow -> status
-__global__ void scr_total_kernel(const int64_t* total, int64_t cap, ScrMisc* misc, int which) {
+// total of the cell list -> misc, overflow -> status
+__global__ void scr_total_kernel(const int64_t* total, int64_t cap, ScrMisc* misc) {
     const long long n = total[0];
-    if (which == 0) misc->ncellA = n; else misc->ncellB = n;
+    misc->ncell = n;
     if (n > cap) misc->status |= 1;
 }
 
@@ -615,40 +629,42 @@ __global__ void scr_total_kernel(const int64_t* total, int64_t cap, ScrMisc* mis
 struct RefineArgs {
     const void* in; int64_t n_in; int dt;
     const double* chirp; int Lc;
-    const int64_t* cells; const ScrMisc* misc; int which;     // which = 0: maximum, 1: candidates
-    int64_t plen, nz; double thresh;
-    double* cell_max;             // which = 0: [ncellA] max of the cell's fp64 lags
-    unsigned* cell_mask;          // which = 1: [ncellB] bit j: zeros-index 14 c + j is a candidate
-    int64_t* cell_cnt;            // which = 1: [ncellB] popcount of the mask (for the ordered compaction)
-    double* dbg;                  // optional [ncell][16] fp64 values (tests)
+    const int64_t* cells; ScrMisc* misc;
+    int64_t plen;
+    double* cell_val;             // [ncell][16] the cell's fp64 lags
+    double* cell_max;             // [ncell] their maximum over the lags that exist (NaN if one of them is)
 };
 #define SCR_REF_THREADS 256
 #define SCR_REF_CHUNK (16 * SCR_REF_THREADS)         /* taps staged per step: 16 per thread */
 // LDS staging keeps the global loads coalesced (a thread's own 31 samples are 124 bytes of a line nobody else in the
 // wave touches at that moment): samples and taps of one 4096-tap chunk go to LDS as doubles, element e at
 // e + (e >> 4) -- a thread then reads its 16 taps and 31 samples at a stride of 17 doubles, which is conflict-free.
+// The grid is persistent (two workgroups per CU, what the LDS allows) and cells are handed out by a counter, so the
+// workgroups finish together whatever the list length; a workgroup's work is one sequence of (cell, chunk) steps, and
+// the raw samples and taps of the next step -- the next cell's first chunk included: thread 0 draws its number while
+// the current cell is still being computed -- are fetched into registers while the current step runs out of LDS.
 template <int DT>
-__global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_kernel(RefineArgs a) {
+__global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineArgs a) {
     constexpr int CH = SCR_REF_CHUNK, TH = SCR_REF_THREADS;
     __shared__ double xs[CH + 16 + (CH + 16) / 16 + 1];
     __shared__ double cs[CH + CH / 16];
     __shared__ double part[TH / 64][16];
     __shared__ double P[16];
+    __shared__ long long s_next;
     typedef typename RawT<DT>::E E;
     if (a.misc->status & 1) return;
-    const long long ncell = a.which == 0 ? a.misc->ncellA : a.misc->ncellB;
+    const long long ncell = a.misc->ncell;
     const int t = threadIdx.x;
     const int nch = (a.Lc + CH - 1) / CH;             // chunks per cell
-    // The grid is fixed (the list length lives on the device): each workgroup takes every gridDim.x-th cell.  Its
-    // work is one sequence of (cell, chunk) steps; the raw samples and taps of step i+1 are fetched into registers
-    // while step i is computed out of LDS, so the global-load latency is paid once per workgroup, not per chunk.
-    const long long mine = blockIdx.x < ncell ? (ncell - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-    const long long nsteps = mine * nch;
+    if (t == 0) s_next = (long long)atomicAdd((unsigned long long*)&a.misc->next, 1ull);
+    __syncthreads();
+    long long cur = s_next;
+    if (cur >= ncell) return;                          // (uniform)
     E xr[17];
     double cr[16];
-    auto fetch = [&](long long step) {
-        const int64_t c = a.cells[blockIdx.x + (step / nch) * gridDim.x];
-        const int k0 = (int)(step % nch) * CH;
+    auto fetch = [&](long long item, int ch) {
+        const int64_t c = a.cells[item];
+        const int k0 = ch * CH;
         const int64_t i0 = GF3_SCR_CELL * c - (a.Lc - 1) + k0;
         const bool inside = i0 >= 0 && i0 + CH + 15 <= a.n_in;
 #pragma unroll
@@ -663,22 +679,26 @@ __global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_kernel(RefineArgs 
             cr[q] = k < a.Lc ? a.chirp[k] : 0.0;
         }
     };
-    if (nsteps > 0) fetch(0);
+    fetch(cur, 0);
     double acc[16];
-    for (long long step = 0; step < nsteps; ++step) {
-        const int ch = (int)(step % nch);
-        const long long ci = blockIdx.x + (step / nch) * gridDim.x;
+    long long pending = 0;                             // (thread 0) the item after `cur`
+    int ch = 0;
+    while (true) {
         if (ch == 0) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.0;
+            if (t == 0) pending = (long long)atomicAdd((unsigned long long*)&a.misc->next, 1ull);
         }
-        __syncthreads();                               // the previous step has been consumed
+        __syncthreads();                               // the previous step has been consumed (and s_next read)
 #pragma unroll
         for (int q = 0; q < 17; ++q) { const int e = t + TH * q; if (e < CH + 15) xs[e + (e >> 4)] = (double)xr[q]; }
 #pragma unroll
         for (int q = 0; q < 16; ++q) { const int e = t + TH * q; cs[e + (e >> 4)] = cr[q]; }
+        const bool last = (ch == nch - 1);
+        if (last && t == 0) s_next = pending;
         __syncthreads();
-        if (step + 1 < nsteps) fetch(step + 1);
+        const long long nx = last ? s_next : cur;
+        if (nx < ncell) fetch(nx, last ? 0 : ch + 1);
         {
             double x[31];
 #pragma unroll
@@ -690,9 +710,9 @@ __global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_kernel(RefineArgs 
                 for (int j = 0; j < 16; ++j) acc[j] = fma(ck, x[kk + j], acc[j]);
             }
         }
-        if (ch != nch - 1) continue;
-        // ---- the cell is complete: reduce the 16 sums over the workgroup and decide
-        const int64_t m0 = GF3_SCR_CELL * a.cells[ci];
+        if (!last) { ++ch; continue; }
+        // ---- the cell is complete: reduce the 16 sums over the workgroup, keep them
+        const int64_t m0 = GF3_SCR_CELL * a.cells[cur];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             double s = acc[j];
@@ -709,53 +729,55 @@ __global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_kernel(RefineArgs 
             double s = 0.0;
             for (int w = 0; w < TH / 64; ++w) s += part[w][t];
             P[t] = s;
-            if (a.dbg) a.dbg[ci * 16 + t] = s;
+            a.cell_val[cur * 16 + t] = s;
         }
         __syncthreads();
-        if (a.which == 0) {
-            if (t == 0) {
-                double mx = -INFINITY;
-                bool nan = false;
-                for (int j = 0; j < 16; ++j) if (m0 + j < a.plen) { mx = fmax(mx, P[j]); nan = nan || !(P[j] == P[j]); }
-                a.cell_max[ci] = nan ? NAN : mx;
-            }
-            continue;
-        }
-        // candidates: the reference's rule on the fp64 values, division by the maximum first (OFDM.py:359-361)
-        bool cand = false;
-        if (t < GF3_SCR_CELL) {
-            const int64_t i = m0 + t;
-            if (i < a.nz) {
-                const double M = a.misc->M;
-                const double p0 = P[t] / M, p1 = P[t + 1] / M, p2 = P[t + 2] / M;
-                cand = ((p1 - p0) * (p2 - p1) <= 0.0) && (p1 > a.thresh);
-            }
-        }
-        const unsigned long long bal = __ballot(cand);
         if (t == 0) {
-            a.cell_mask[ci] = (unsigned)(bal & 0x3fffull);
-            a.cell_cnt[ci] = __popcll(bal & 0x3fffull);
+            double mx = -INFINITY;
+            bool nan = false;
+            for (int j = 0; j < 16; ++j) if (m0 + j < a.plen) { mx = fmax(mx, P[j]); nan = nan || !(P[j] == P[j]); }
+            a.cell_max[cur] = nan ? NAN : mx;
         }
+        if (nx >= ncell) break;                        // (uniform)
+        cur = nx; ch = 0;
     }
 }
 
-// maximum over the re-evaluated cells -> misc->M and the screening limit for the candidates
-__global__ void scr_max_kernel(const double* cell_max, ScrMisc* misc, double thresh) {
+// maximum over the re-evaluated cells -> misc->M
+__global__ void scr_max_kernel(const double* cell_max, ScrMisc* misc) {
     __shared__ double scratch[16];
     if (misc->status & 1) return;
     double m = -INFINITY;
-    const long long n = misc->ncellA;
+    const long long n = misc->ncell;
     for (long long i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, cell_max[i]);
     bool nan = false;
     for (long long i = threadIdx.x; i < n; i += blockDim.x) nan = nan || !(cell_max[i] == cell_max[i]);
     m = block_max(m, scratch);
     const int anynan = __syncthreads_or(nan ? 1 : 0);
-    if (threadIdx.x == 0) {
-        if (anynan) m = NAN;                                          // np.amax propagates NaN
-        misc->M = m;
-        const bool filt = m > 0.0 && thresh > 0.0 && m < INFINITY && thresh < INFINITY;
-        misc->lim = filt ? thresh * m * (1.0 - 1e-6) : -INFINITY;     // same prefilter as pk_candidates
+    if (threadIdx.x == 0) misc->M = anynan ? NAN : m;                     // (np.amax propagates NaN)
+}
+
+// candidates of every listed cell: the reference's rule on the fp64 values, division by the maximum first
+// (OFDM.py:359-361).  One thread per cell; bit j of the mask: zeros-index 14 c + j is a candidate.
+__global__ void scr_decide_kernel(const int64_t* cells, const double* cell_val, ScrMisc* misc, int64_t nz, double thresh,
+                                  unsigned* cell_mask, int64_t* cell_cnt) {
+    if (misc->status & 1) return;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= misc->ncell) return;
+    const double M = misc->M;
+    const int64_t m0 = GF3_SCR_CELL * cells[i];
+    double p[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) p[j] = cell_val[i * 16 + j] / M;
+    unsigned mk = 0;
+#pragma unroll
+    for (int j = 0; j < GF3_SCR_CELL; ++j) {
+        const bool cand = (m0 + j < nz) && ((p[j + 1] - p[j]) * (p[j + 2] - p[j + 1]) <= 0.0) && (p[j + 1] > thresh);
+        mk |= cand ? (1u << j) : 0u;
     }
+    cell_mask[i] = mk;
+    cell_cnt[i] = __popc(mk);
+    if (mk) atomicAdd((unsigned long long*)&misc->nhit, 1ull);
 }
 
 // ordered expansion of the cell masks into zeros-indices
@@ -763,7 +785,7 @@ __global__ void scr_expand_kernel(const int64_t* cells, const unsigned* cell_mas
                                   int64_t* cand, int64_t cap) {
     if (misc->status & 1) return;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= misc->ncellB) return;
+    if (i >= misc->ncell) return;
     unsigned m = cell_mask[i];
     int64_t o = offsets[i];
     const int64_t base = GF3_SCR_CELL * cells[i];

@@ -276,10 +276,10 @@ class Engine:
 
     def sync_stream_info(self):
         """Of the last sync_stream call: dict(path=0 screened | 1 fp64 after a non-selective screen | 2 fp64,
-        cells_max, cells_cand, candidates)."""
+        cells = cells of 14 lags re-evaluated in fp64, cells_hit = those holding a candidate, candidates)."""
         out = (C.c_int64 * 4)()
         self._check(self.lib.gf3_sync_stream_info(self._h, out))
-        return dict(path=int(out[0]), cells_max=int(out[1]), cells_cand=int(out[2]), candidates=int(out[3]))
+        return dict(path=int(out[0]), cells=int(out[1]), cells_hit=int(out[2]), candidates=int(out[3]))
 
     def debug_stream_screen(self, x):
         """The fp32 screening pass alone (tests): (P32 [n+Lc-1] float32, block maxima, block error bounds, hop)."""

@@ -178,7 +178,7 @@ int gf3_sync_stream(gf3_ctx *ctx, const void *d_r, int64_t n,
  */
 int gf3_sync_stream_mode(gf3_ctx *ctx, int32_t mode);
 /* h_out4 (host): of the last gf3_sync_stream call: path (0 screened, 1 fp64 after a non-selective screen, 2 fp64),
- * cells re-evaluated for the maximum, cells re-evaluated for candidates, candidates found */
+ * cells (of 14 lags) re-evaluated in fp64, cells among them that hold a candidate, candidates found */
 int gf3_sync_stream_info(const gf3_ctx *ctx, int64_t *h_out4);
 /* tests: the fp32 screening pass alone.  d_p32 [n+Lc-1] float; d_blk [2*nblk] float: per block of *h_hop lags its
  * maximum, then the bound on |P32 - P| of its lags (nblk = ceil((n+Lc-1) / hop)) */

@@ -415,7 +415,7 @@ def test_config3_full_size_stream():
     del Pfull
     got_peaks = eng.sync_stream(r).cpu().numpy()
     info = eng.sync_stream_info()
-    assert info["path"] == 0 and info["cells_cand"] < 8 * (F + 1), info      # fp32 screen + fp64 decisions, a few cells per chirp
+    assert info["path"] == 0 and info["cells"] < 8 * (F + 1) and info["cells_hit"] >= F + 1, info      # fp32 screen + fp64 decisions, a few cells per chirp
     assert len(want_peaks) == F + 1
     assert np.array_equal(got_peaks, want_peaks)
     assert np.array_equal(starts.cpu().numpy(), want_peaks[:-1] + 2)
@@ -808,7 +808,7 @@ def test_stream_sync_screened_equals_fp64_path(name):
             got = eng.sync_stream(x).cpu().numpy()
             info = eng.sync_stream_info()
             assert np.array_equal(got, want)
-            assert info["path"] == 0 and 0 < info["cells_max"] <= 64 and info["cells_cand"] <= 64 * len(want), info
+            assert info["path"] == 0 and 0 < info["cells_hit"] <= info["cells"] <= 64 * len(want), info
         eng.sync_stream_mode(1)
         assert np.array_equal(eng.sync_stream(x).cpu().numpy(), want)
         assert eng.sync_stream_info()["path"] == 2
