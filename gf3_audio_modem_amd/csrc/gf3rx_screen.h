@@ -650,38 +650,47 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
     __shared__ double cs[CH + CH / 16];
     __shared__ double part[TH / 64][16];
     __shared__ double P[16];
-    __shared__ long long s_next;
+    __shared__ long long s_next[2];                    // the workgroup's next item and its cell number
     typedef typename RawT<DT>::E E;
     if (a.misc->status & 1) return;
     const long long ncell = a.misc->ncell;
     const int t = threadIdx.x;
     const int nch = (a.Lc + CH - 1) / CH;             // chunks per cell
-    if (t == 0) s_next = (long long)atomicAdd((unsigned long long*)&a.misc->next, 1ull);
+    if (t == 0) {
+        const long long it = (long long)atomicAdd((unsigned long long*)&a.misc->next, 1ull);
+        s_next[0] = it; s_next[1] = it < ncell ? a.cells[it] : 0;
+    }
     __syncthreads();
-    long long cur = s_next;
+    long long cur = s_next[0];
+    int64_t cur_cell = s_next[1];
     if (cur >= ncell) return;                          // (uniform)
     E xr[17];
     double cr[16];
-    auto fetch = [&](long long item, int ch) {
-        const int64_t c = a.cells[item];
+    // (no load here depends on another load, and none sits under a branch: out-of-range elements are read from a
+    //  clamped address and replaced -- 33 loads issue back to back and land while the current step is computed)
+    auto fetch = [&](int64_t c, int ch) {
         const int k0 = ch * CH;
         const int64_t i0 = GF3_SCR_CELL * c - (a.Lc - 1) + k0;
-        const bool inside = i0 >= 0 && i0 + CH + 15 <= a.n_in;
+        const int64_t last_i = a.n_in - 1;
 #pragma unroll
         for (int q = 0; q < 17; ++q) {
             const int e = t + TH * q;
             const int64_t i = i0 + e;
-            xr[q] = (e < CH + 15 && (inside || (i >= 0 && i < a.n_in))) ? ((const E*)a.in)[i] : (E)0;
+            const int64_t ic = i < 0 ? 0 : (i > last_i ? last_i : i);
+            const E val = ((const E*)a.in)[ic];
+            xr[q] = (e < CH + 15 && i == ic) ? val : (E)0;
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int k = k0 + t + TH * q;
-            cr[q] = k < a.Lc ? a.chirp[k] : 0.0;
+            const double val = a.chirp[k < a.Lc ? k : a.Lc - 1];
+            cr[q] = k < a.Lc ? val : 0.0;
         }
     };
-    fetch(cur, 0);
+    fetch(cur_cell, 0);
     double acc[16];
-    long long pending = 0;                             // (thread 0) the item after `cur`
+    long long pending = 0;                             // (thread 0) the item after `cur` ...
+    int64_t pending_cell = 0;                          // ... and its cell number
     int ch = 0;
     while (true) {
         if (ch == 0) {
@@ -689,16 +698,20 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
             for (int j = 0; j < 16; ++j) acc[j] = 0.0;
             if (t == 0) pending = (long long)atomicAdd((unsigned long long*)&a.misc->next, 1ull);
         }
+        // (one step after the draw, so that neither round trip is waited for: the counter's answer is back by now and
+        //  the cell number has the rest of the cell's steps to arrive)
+        if (t == 0 && (ch == 1 || (ch == 0 && nch == 1))) pending_cell = pending < ncell ? a.cells[pending] : 0;
         __syncthreads();                               // the previous step has been consumed (and s_next read)
 #pragma unroll
         for (int q = 0; q < 17; ++q) { const int e = t + TH * q; if (e < CH + 15) xs[e + (e >> 4)] = (double)xr[q]; }
 #pragma unroll
         for (int q = 0; q < 16; ++q) { const int e = t + TH * q; cs[e + (e >> 4)] = cr[q]; }
         const bool last = (ch == nch - 1);
-        if (last && t == 0) s_next = pending;
+        if (last && t == 0) { s_next[0] = pending; s_next[1] = pending_cell; }
         __syncthreads();
-        const long long nx = last ? s_next : cur;
-        if (nx < ncell) fetch(nx, last ? 0 : ch + 1);
+        const long long nx = last ? s_next[0] : cur;
+        const int64_t nx_cell = last ? s_next[1] : cur_cell;
+        if (nx < ncell) fetch(nx_cell, last ? 0 : ch + 1);
         {
             double x[31];
 #pragma unroll
@@ -712,7 +725,7 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
         }
         if (!last) { ++ch; continue; }
         // ---- the cell is complete: reduce the 16 sums over the workgroup, keep them
-        const int64_t m0 = GF3_SCR_CELL * a.cells[cur];
+        const int64_t m0 = GF3_SCR_CELL * cur_cell;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             double s = acc[j];
@@ -739,7 +752,7 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
             a.cell_max[cur] = nan ? NAN : mx;
         }
         if (nx >= ncell) break;                        // (uniform)
-        cur = nx; ch = 0;
+        cur = nx; cur_cell = nx_cell; ch = 0;
     }
 }
 
