@@ -635,124 +635,126 @@ struct RefineArgs {
     double* cell_max;             // [ncell] their maximum over the lags that exist (NaN if one of them is)
 };
 #define SCR_REF_THREADS 256
-#define SCR_REF_CHUNK (16 * SCR_REF_THREADS)         /* taps staged per step: 16 per thread */
-// LDS staging keeps the global loads coalesced (a thread's own 31 samples are 124 bytes of a line nobody else in the
-// wave touches at that moment): samples and taps of one 4096-tap chunk go to LDS as doubles, element e at
-// e + (e >> 4) -- a thread then reads its 16 taps and 31 samples at a stride of 17 doubles, which is conflict-free.
-// The grid is persistent (two workgroups per CU, what the LDS allows) and cells are handed out by a counter, so the
-// workgroups finish together whatever the list length; a workgroup's work is one sequence of (cell, chunk) steps, and
-// the raw samples and taps of the next step -- the next cell's first chunk included: thread 0 draws its number while
-// the current cell is still being computed -- are fetched into registers while the current step runs out of LDS.
+#define SCR_REF_WT 1024                              /* taps staged per wave and step: 16 per lane */
+// Every WAVE works on its own: it draws a cell from the counter, walks the cell's taps 1024 at a time and owns a
+// private slice of LDS for the staging, so there is no workgroup barrier anywhere and the 8 waves of a CU drift apart
+// -- one wave's LDS phase runs under another's fma phase (with workgroup-wide steps and two barriers per step the
+// phases of all waves lined up and the kernel ran at 20 % of the fp64 rate).
+// Staging keeps the global loads coalesced (a lane's own 31 samples are 124 bytes of a line nobody else in the wave
+// touches at that moment): samples and taps go to LDS as doubles, element e at e + (e >> 4) -- a lane then reads its 16
+// taps and 31 samples at a stride of 17 doubles, which is conflict-free.  The raw samples and taps of the next step
+// (the next cell's first step included: its number is drawn while the current cell is being computed) are fetched
+// into registers while the current step runs out of LDS; no load depends on another load of the same step.
 template <int DT>
 __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineArgs a) {
-    constexpr int CH = SCR_REF_CHUNK, TH = SCR_REF_THREADS;
-    __shared__ double xs[CH + 16 + (CH + 16) / 16 + 1];
-    __shared__ double cs[CH + CH / 16];
-    __shared__ double part[TH / 64][16];
-    __shared__ double P[16];
-    __shared__ long long s_next[2];                    // the workgroup's next item and its cell number
+    constexpr int WT = SCR_REF_WT, NW = SCR_REF_THREADS / 64;
+    __shared__ double xs_all[NW][WT + 16 + (WT + 16) / 16 + 1];
+    __shared__ double cs_all[NW][WT + WT / 16];
     typedef typename RawT<DT>::E E;
     if (a.misc->status & 1) return;
     const long long ncell = a.misc->ncell;
-    const int t = threadIdx.x;
-    const int nch = (a.Lc + CH - 1) / CH;             // chunks per cell
-    if (t == 0) {
-        const long long it = (long long)atomicAdd((unsigned long long*)&a.misc->next, 1ull);
-        s_next[0] = it; s_next[1] = it < ncell ? a.cells[it] : 0;
-    }
-    __syncthreads();
-    long long cur = s_next[0];
-    int64_t cur_cell = s_next[1];
-    if (cur >= ncell) return;                          // (uniform)
+    const int lane = threadIdx.x & 63;
+    double* xs = xs_all[threadIdx.x >> 6];
+    double* cs = cs_all[threadIdx.x >> 6];
+    const int nst = (a.Lc + WT - 1) / WT;             // steps per cell
+    const int look = nst > 1 ? 1 : 0;                 // the step at which the next cell's number is looked up
+    auto first_lane64 = [](unsigned long long v) -> long long {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    unsigned long long drawn = 0;
+    if (lane == 0) drawn = atomicAdd((unsigned long long*)&a.misc->next, 1ull);
+    long long cur = first_lane64(drawn);
+    if (cur >= ncell) return;                          // (per wave: nothing below synchronises across waves)
+    int64_t cur_cell = a.cells[cur];
     E xr[17];
     double cr[16];
-    // (no load here depends on another load, and none sits under a branch: out-of-range elements are read from a
-    //  clamped address and replaced -- 33 loads issue back to back and land while the current step is computed)
-    auto fetch = [&](int64_t c, int ch) {
-        const int k0 = ch * CH;
+    auto fetch = [&](int64_t c, int st) {
+        const int k0 = st * WT;
         const int64_t i0 = GF3_SCR_CELL * c - (a.Lc - 1) + k0;
-        const int64_t last_i = a.n_in - 1;
+        if (i0 >= 0 && i0 + WT + 15 <= a.n_in) {        // (uniform) the whole step lies inside the stream
+            const E* base = (const E*)a.in + i0;
 #pragma unroll
-        for (int q = 0; q < 17; ++q) {
-            const int e = t + TH * q;
-            const int64_t i = i0 + e;
-            const int64_t ic = i < 0 ? 0 : (i > last_i ? last_i : i);
-            const E val = ((const E*)a.in)[ic];
-            xr[q] = (e < CH + 15 && i == ic) ? val : (E)0;
+            for (int q = 0; q < 16; ++q) xr[q] = base[lane + 64 * q];
+            xr[16] = base[WT + (lane < 15 ? lane : 14)];
+        } else {
+            const int64_t last_i = a.n_in - 1;
+#pragma unroll
+            for (int q = 0; q < 17; ++q) {
+                const int64_t i = i0 + lane + 64 * q;
+                const int64_t ic = i < 0 ? 0 : (i > last_i ? last_i : i);
+                const E val = ((const E*)a.in)[ic];
+                xr[q] = (i == ic) ? val : (E)0;
+            }
         }
+        if (k0 + WT <= a.Lc) {                          // (uniform)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int k = k0 + t + TH * q;
-            const double val = a.chirp[k < a.Lc ? k : a.Lc - 1];
-            cr[q] = k < a.Lc ? val : 0.0;
+            for (int q = 0; q < 16; ++q) cr[q] = a.chirp[k0 + lane + 64 * q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = k0 + lane + 64 * q;
+                const double val = a.chirp[k < a.Lc ? k : a.Lc - 1];
+                cr[q] = k < a.Lc ? val : 0.0;
+            }
         }
     };
     fetch(cur_cell, 0);
     double acc[16];
-    long long pending = 0;                             // (thread 0) the item after `cur` ...
+    long long pending = 0;                             // the item after `cur` ...
     int64_t pending_cell = 0;                          // ... and its cell number
-    int ch = 0;
+    int st = 0;
     while (true) {
-        if (ch == 0) {
+        if (st == 0) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-            if (t == 0) pending = (long long)atomicAdd((unsigned long long*)&a.misc->next, 1ull);
+            drawn = 0;
+            if (lane == 0) drawn = atomicAdd((unsigned long long*)&a.misc->next, 1ull);
         }
-        // (one step after the draw, so that neither round trip is waited for: the counter's answer is back by now and
-        //  the cell number has the rest of the cell's steps to arrive)
-        if (t == 0 && (ch == 1 || (ch == 0 && nch == 1))) pending_cell = pending < ncell ? a.cells[pending] : 0;
-        __syncthreads();                               // the previous step has been consumed (and s_next read)
+        if (st == look) {                              // (one step after the draw: the counter's answer is back by now, and
+            pending = first_lane64(drawn);             //  the cell number has the rest of the cell's steps to arrive)
+            pending_cell = pending < ncell ? a.cells[pending] : 0;
+        }
+        // registers -> this wave's LDS (its reads of the previous step were issued before these writes: LDS serves a
+        // wave's instructions in order)
 #pragma unroll
-        for (int q = 0; q < 17; ++q) { const int e = t + TH * q; if (e < CH + 15) xs[e + (e >> 4)] = (double)xr[q]; }
+        for (int q = 0; q < 17; ++q) { const int e = lane + 64 * q; if (q < 16 || lane < 15) xs[e + (e >> 4)] = (double)xr[q]; }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { const int e = t + TH * q; cs[e + (e >> 4)] = cr[q]; }
-        const bool last = (ch == nch - 1);
-        if (last && t == 0) { s_next[0] = pending; s_next[1] = pending_cell; }
-        __syncthreads();
-        const long long nx = last ? s_next[0] : cur;
-        const int64_t nx_cell = last ? s_next[1] : cur_cell;
-        if (nx < ncell) fetch(nx_cell, last ? 0 : ch + 1);
+        for (int q = 0; q < 16; ++q) { const int e = lane + 64 * q; cs[e + (e >> 4)] = cr[q]; }
+        asm volatile("" ::: "memory");
+        const bool last = (st == nst - 1);
+        const long long nx = last ? pending : cur;
+        const int64_t nx_cell = last ? pending_cell : cur_cell;
+        if (nx < ncell) fetch(nx_cell, last ? 0 : st + 1);
         {
             double x[31];
 #pragma unroll
-            for (int i = 0; i < 31; ++i) x[i] = xs[17 * t + i + (i >> 4)];
+            for (int i = 0; i < 31; ++i) x[i] = xs[17 * lane + i + (i >> 4)];
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                const double ck = cs[17 * t + kk];
+                const double ck = cs[17 * lane + kk];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) acc[j] = fma(ck, x[kk + j], acc[j]);
             }
         }
-        if (!last) { ++ch; continue; }
-        // ---- the cell is complete: reduce the 16 sums over the workgroup, keep them
+        asm volatile("" ::: "memory");
+        if (!last) { ++st; continue; }
+        // ---- the cell is complete: sum the 16 partial sums over the wave, keep them
         const int64_t m0 = GF3_SCR_CELL * cur_cell;
+        double mine = 0.0, mx = -INFINITY;
+        bool nan = false;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             double s = acc[j];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-            acc[j] = s;
+            mine = (lane == j) ? s : mine;
+            if (m0 + j < a.plen) { mx = fmax(mx, s); nan = nan || !(s == s); }
         }
-        if ((t & 63) == 0) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) part[t >> 6][j] = acc[j];
-        }
-        __syncthreads();
-        if (t < 16) {
-            double s = 0.0;
-            for (int w = 0; w < TH / 64; ++w) s += part[w][t];
-            P[t] = s;
-            a.cell_val[cur * 16 + t] = s;
-        }
-        __syncthreads();
-        if (t == 0) {
-            double mx = -INFINITY;
-            bool nan = false;
-            for (int j = 0; j < 16; ++j) if (m0 + j < a.plen) { mx = fmax(mx, P[j]); nan = nan || !(P[j] == P[j]); }
-            a.cell_max[cur] = nan ? NAN : mx;
-        }
+        if (lane < 16) a.cell_val[cur * 16 + lane] = mine;
+        if (lane == 0) a.cell_max[cur] = nan ? NAN : mx;
         if (nx >= ncell) break;                        // (uniform)
-        cur = nx; cur_cell = nx_cell; ch = 0;
+        cur = nx; cur_cell = nx_cell; st = 0;
     }
 }
 
