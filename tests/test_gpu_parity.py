@@ -923,7 +923,7 @@ def test_new_abi_error_paths():
     """gf3_sync_stream_mode / gf3_equalise_known_h reject what the header says they reject."""
     g = load("g1_n1024_qpsk")
     eng = engine_for(params_of(g))
-    for bad in (-1, 3):
+    for bad in (-1, 4):
         with pytest.raises(ValueError, match="mode"):
             eng.sync_stream_mode(bad)
     x = torch.zeros(5000, dtype=torch.float64, device="cuda")
