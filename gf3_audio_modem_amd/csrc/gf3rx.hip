@@ -934,7 +934,8 @@ __global__ void pk_candidates(const double* __restrict__ P, int64_t nz, const do
 }
 #define SCAN_PER 16
 // n_dev (optional, device): scan only the first min(n, *n_dev) counts -- lists whose length lives on the device
-__global__ void pk_scan(const int64_t* counts, int64_t n, int64_t* offsets, int64_t* total, const long long* n_dev = nullptr) {
+__global__ void pk_scan(const int64_t* counts, int64_t n, int64_t* offsets, int64_t* total, const long long* n_dev = nullptr,
+                        const long long* void_if_odd = nullptr) {
     // one workgroup, exclusive scan; each thread owns SCAN_PER consecutive counts per step
     __shared__ int64_t wsum[16];
     __shared__ int64_t carry;
@@ -961,7 +962,9 @@ __global__ void pk_scan(const int64_t* counts, int64_t n, int64_t* offsets, int6
         if (threadIdx.x == 0) carry += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) total[0] = carry;
+    // (void_if_odd: the screened sync's status word -- a call that is about to fall back must not leave a list length
+    //  that was summed over counts nobody wrote)
+    if (threadIdx.x == 0) total[0] = (void_if_odd && (void_if_odd[0] & 1)) ? 0 : carry;
 }
 // sequential suppression (OFDM.py:364-370) over the sorted candidate list: an accepted candidate i suppresses
 // everything up to i+Lc, so the next survivor is succ(k) = the first candidate >= i+Lc+1, and the accepted set is
@@ -2031,7 +2034,7 @@ extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64
 struct StreamWs { int64_t plen, nz, nb_max, nb_c, nblk, nwin; size_t o_P, o_part, o_cnt, o_off, o_cand, o_misc, o_spec, total;
                   // screened path (gf3rx_screen.h); P32 overlays o_P, the per-workgroup counts / offsets overlay o_cnt / o_off
                   int64_t s_nblk, s_ncell, s_nwg, s_cap;
-                  size_t o_sblk, o_smisc, o_cell, o_cmax, o_cval, o_mask, o_ccnt, o_coff; };
+                  size_t o_sblk, o_smisc, o_segm, o_cell, o_cval, o_mask, o_ccnt, o_coff; };
 static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
     StreamWs w;
     w.plen = n + c->Lc - 1; w.nz = w.plen - 2;
@@ -2056,14 +2059,14 @@ static StreamWs stream_ws(const gf3_ctx* c, int64_t n) {
         w.s_nblk = (w.plen + c->scr.H - 1) / c->scr.H;
         w.s_ncell = (w.nz + GF3_SCR_CELL - 1) / GF3_SCR_CELL;
         if (w.s_ncell < 1) w.s_ncell = 1;
-        w.s_nwg = (w.s_ncell + SCR_LIST_THREADS * SCR_LIST_GROUPS - 1) / (SCR_LIST_THREADS * SCR_LIST_GROUPS);
+        w.s_nwg = (w.s_ncell + 64 * SCR_LIST_SEGS - 1) / (64 * SCR_LIST_SEGS);
         // work list: a sixteenth of all cells (a clean stream lists two or three cells per chirp, one chirp per > 5 Lc
         // samples = 25 cells at the very least), never fewer than 4096
         w.s_cap = w.s_ncell / 16 > 4096 ? w.s_ncell / 16 : 4096;
         w.o_sblk = take((size_t)w.s_nblk * 8);                 // blk_max | blk_err (float each)
         w.o_smisc = take(sizeof(ScrMisc) + 16);                // (+ the screen's running lower bound of the maximum)
+        w.o_segm = take((size_t)w.s_nwg * SCR_LIST_SEGS * 8);  // hit mask per segment of 64 cells
         w.o_cell = take((size_t)w.s_cap * 8);
-        w.o_cmax = take((size_t)w.s_cap * 8);
         w.o_cval = take((size_t)w.s_cap * 16 * 8);
         w.o_mask = take((size_t)w.s_cap * 4);
         w.o_ccnt = take((size_t)w.s_cap * 8);
@@ -2118,43 +2121,47 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
     int64_t* total = (int64_t*)(base + w.o_misc + 8);
     int64_t* np = (int64_t*)(base + w.o_misc + 16);
     int64_t* cand = (int64_t*)(base + w.o_cand);
+    unsigned long long* segm = (unsigned long long*)(base + w.o_segm);
     int64_t* cell = (int64_t*)(base + w.o_cell);
-    double* cmax = (double*)(base + w.o_cmax);
     double* cval = (double*)(base + w.o_cval);
     unsigned* mask = (unsigned*)(base + w.o_mask);
     int64_t* ccnt = (int64_t*)(base + w.o_ccnt);
     int64_t* coff = (int64_t*)(base + w.o_coff);
     const int dt = c->cfg.in_dtype;
+    // (the scalars of the call, and behind them the screen's running lower bound of the maximum: float bits, 0 = none yet)
+    HIPCHK(c, hipMemsetAsync(misc, 0, sizeof(ScrMisc) + 16, st));
     {   // 1. every lag in fp32, with a bound per block
-        int* run_lo = (int*)(base + w.o_smisc + sizeof(ScrMisc));       // running lower bound of the maximum (float bits; 0 = none yet)
-        HIPCHK(c, hipMemsetAsync(run_lo, 0, sizeof(int), st));
         ScreenArgs a{d_r, n, dt, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, w.s_nblk, w.plen,
-                     P32, blk_max, blk_err, run_lo, (float)c->cfg.thresh, nullptr, nullptr, 0};
+                     P32, blk_max, blk_err, (int*)(base + w.o_smisc + sizeof(ScrMisc)), (float)c->cfg.thresh, nullptr, nullptr, 0};
         HIPCHK(c, launch_screen(c, a, c->stream_mode == 3, st));
     }
-    // 2. the cells whose lags the bounds cannot exclude, in ascending order (count, scan, write)
-    hipLaunchKernelGGL(scr_mlo_kernel, dim3(1), dim3(1024), 0, st, (const float*)blk_max, (const float*)blk_err, w.s_nblk, misc, c->cfg.thresh);
-    hipLaunchKernelGGL(scr_cells_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
-                       (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, cnt, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0);
-    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.s_nwg, offs, total, (const long long*)nullptr);
-    hipLaunchKernelGGL(scr_total_kernel, dim3(1), dim3(1), 0, st, (const int64_t*)total, w.s_cap, misc);
-    hipLaunchKernelGGL(scr_cells_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
-                       (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, cnt, (const int64_t*)offs, cell, w.s_cap);
-    {   // 3. their lags in fp64, once; the maximum; the reference's rule on those values
-        RefineArgs a{d_r, n, dt, c->d_chirp, c->Lc, cell, misc, w.plen, cval, cmax};
+    // 2. the cells whose lags the bounds cannot exclude, in ascending order (flag + count, scan, scatter)
+    {
+        int64_t g = (w.s_nblk + SCR_MLO_THREADS * 4 - 1) / (SCR_MLO_THREADS * 4);
+        g = g < 1 ? 1 : (g > 128 ? 128 : g);
+        hipLaunchKernelGGL(scr_mlo_kernel, dim3((unsigned)g), dim3(SCR_MLO_THREADS), 0, st, (const float*)blk_max, (const float*)blk_err, w.s_nblk, misc,
+                           (double)c->cfg.thresh);
+    }
+    hipLaunchKernelGGL(scr_flag_kernel, dim3((unsigned)w.s_nwg), dim3(SCR_LIST_THREADS), 0, st, (const float*)P32, (const float*)blk_max,
+                       (const float*)blk_err, sp.H, w.plen, w.s_ncell, (const ScrMisc*)misc, segm, cnt);
+    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.s_nwg, offs, total, (const long long*)nullptr, (const long long*)nullptr);
+    hipLaunchKernelGGL(scr_scatter_kernel, dim3((unsigned)w.s_nwg), dim3(64), 0, st, (const unsigned long long*)segm, (const int64_t*)cnt,
+                       (const int64_t*)offs, (const int64_t*)total, misc, cell, w.s_cap);
+    {   // 3. their lags in fp64, once (the maximum is kept as the cells complete); the reference's rule on those values
+        RefineArgs a{d_r, n, dt, c->d_chirp, c->Lc, cell, misc, w.plen, cval};
         const int64_t slots = 2 * (int64_t)c->n_cu;                         // (the LDS staging allows two workgroups per CU)
-        const unsigned grid = (unsigned)(w.s_cap < slots ? w.s_cap : slots);
+        const int64_t wgs = (w.s_cap + 3) / 4;                               // (a wave per cell at a time)
+        const unsigned grid = (unsigned)(wgs < slots ? wgs : slots);
         DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine_kernel<DTC>), dim3(grid), dim3(SCR_REF_THREADS), 0, st, a));
         HIPCHK(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(scr_max_kernel, dim3(1), dim3(1024), 0, st, (const double*)cmax, misc);
     hipLaunchKernelGGL(scr_decide_kernel, dim3((unsigned)((w.s_cap + 255) / 256)), dim3(256), 0, st, (const int64_t*)cell, (const double*)cval, misc,
                        w.nz, (double)c->cfg.thresh, mask, ccnt);
     // 4. candidates in ascending order, suppression walk
-    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)ccnt, w.s_cap, coff, total, (const long long*)&misc->ncell);
+    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)ccnt, w.s_cap, coff, total, (const long long*)&misc->ncell,
+                       (const long long*)&misc->status);
     hipLaunchKernelGGL(scr_expand_kernel, dim3((unsigned)((w.s_cap + 255) / 256)), dim3(256), 0, st, (const int64_t*)cell, (const unsigned*)mask,
                        (const int64_t*)coff, (const ScrMisc*)misc, cand, w.nz + 2);
-    hipLaunchKernelGGL(scr_guard_kernel, dim3(1), dim3(1), 0, st, (const ScrMisc*)misc, total);
     hipLaunchKernelGGL(pk_nms, dim3(1), dim3(NMS_THREADS), 0, st, (const int64_t*)cand, (const int64_t*)total,
                        (int64_t)c->Lc, w.nz, d_peaks, cap, np);
     HIPCHK(c, hipGetLastError());
@@ -2252,7 +2259,7 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     hipLaunchKernelGGL(pk_max_final, dim3(1), dim3(256), 0, st, (const double*)part, (int)w.nb_max, mx);
     hipLaunchKernelGGL(pk_candidates, dim3((unsigned)w.nb_c), dim3(PK_THREADS), 0, st, (const double*)P, w.nz,
                        (const double*)mx, c->cfg.thresh, cnt, (const int64_t*)nullptr, (int64_t*)nullptr);
-    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.nb_c, offs, total, (const long long*)nullptr);
+    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, w.nb_c, offs, total, (const long long*)nullptr, (const long long*)nullptr);
     hipLaunchKernelGGL(pk_candidates, dim3((unsigned)w.nb_c), dim3(PK_THREADS), 0, st, (const double*)P, w.nz,
                        (const double*)mx, c->cfg.thresh, cnt, (const int64_t*)offs, cand);
     hipLaunchKernelGGL(pk_nms, dim3(1), dim3(NMS_THREADS), 0, st, (const int64_t*)cand, (const int64_t*)total,

@@ -505,54 +505,77 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
 }
 
 // ---------------------------------------------------------------- screening bookkeeping
-struct ScrMisc {                  // device-resident scalars of one gf3_sync_stream call
+struct ScrMisc {                  // device-resident scalars of one gf3_sync_stream call (zeroed by the host before the screen)
     double Mlo;                   // best lower bound of the maximum: max_b (blk_max - blk_err)
     double M;                     // the maximum (fp64 re-evaluation)
     double lim;                   // listing level: a lag whose upper bound stays below it can neither be the maximum nor pass the threshold
     long long ncell;              // cells listed (and re-evaluated)
     long long nhit;               // of those, cells that hold a candidate
     long long status;             // bit 0: the work list overflowed -> the caller falls back to the all-fp64 path
-    long long next;               // work counter of scr_refine_kernel
+    unsigned long long next;      // work counter of scr_refine_kernel
+    unsigned long long mlo_key;   // running maximum of (blk_max - blk_err) as an ordered key (0: none yet)
+    unsigned long long m_key;     // running maximum of the fp64 values, same encoding
+    unsigned int mlo_done;        // workgroups of scr_mlo_kernel that have contributed
+    unsigned int m_nan;           // a re-evaluated lag was NaN (np.amax then returns NaN)
 };
+// order-preserving map double -> uint64 (every finite or infinite value maps above 0, so 0 can mean "nothing yet")
+GF3_DEV unsigned long long scr_key(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+GF3_DEV double scr_unkey(unsigned long long k) {
+    if (k == 0) return -INFINITY;
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+}
 
 // One list serves both questions.  With Mlo <= M:  a lag that could be the maximum has an upper bound >= Mlo, a lag
 // that could pass the threshold has one >= thresh M (1 - 1e-6) >= thresh Mlo (1 - 1e-6); so every lag that matters has
 // an upper bound >= lim = min(Mlo, thresh Mlo (1 - 1e-6)), known BEFORE any fp64 value is.  The cells under those lags
 // are re-evaluated once; M is the largest of their fp64 values and the rule is then applied to the same values.
-__global__ void scr_mlo_kernel(const float* blk_max, const float* blk_err, int64_t nblk, ScrMisc* misc, double thresh) {
+// (A few dozen workgroups: one workgroup's loop over 80 000 blocks was 40 us of load latency.  The last one to
+//  contribute turns the key into Mlo and lim.)
+#define SCR_MLO_THREADS 256
+__global__ __launch_bounds__(SCR_MLO_THREADS) void scr_mlo_kernel(const float* blk_max, const float* blk_err, int64_t nblk, ScrMisc* misc, double thresh) {
     __shared__ double scratch[16];
-    double m = -INFINITY;
-    for (int64_t i = threadIdx.x; i < nblk; i += blockDim.x) m = fmax(m, (double)blk_max[i] - (double)blk_err[i]);
+    double m = -INFINITY;                                                     // (fmax drops NaN blocks here; their lags are kept by scr_flag_kernel)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmax(m, (double)blk_max[i] - (double)blk_err[i]);
     m = block_max(m, scratch);
     if (threadIdx.x == 0) {
-        misc->Mlo = m; misc->status = 0; misc->ncell = misc->nhit = 0; misc->next = 0;
-        // (the prefilter of pk_candidates: only a positive finite maximum and threshold exclude anything; a NaN bound
-        //  lists everything, which overflows the list and falls back)
-        const bool filt = m > 0.0 && thresh > 0.0 && m < INFINITY && thresh < INFINITY;
-        misc->lim = filt ? fmin(m, thresh * m * (1.0 - 1e-6)) : (m == m ? -INFINITY : NAN);
+        if (m > -INFINITY) atomicMax(&misc->mlo_key, scr_key(m));
+        __threadfence();
+        if (atomicAdd(&misc->mlo_done, 1u) == gridDim.x - 1) {
+            __threadfence();
+            m = scr_unkey(atomicMax(&misc->mlo_key, 0ull));
+            misc->Mlo = m;
+            // (the prefilter of pk_candidates: only a positive finite maximum and threshold exclude anything)
+            const bool filt = m > 0.0 && thresh > 0.0 && m < INFINITY && thresh < INFINITY;
+            misc->lim = filt ? fmin(m, thresh * m * (1.0 - 1e-6)) : -INFINITY;
+        }
     }
 }
 
 // Cells: cell c = centre lags m = 1 + 14 c .. 14 + 14 c of the full correlation (zeros-indices i = m - 1); its
 // refinement evaluates the 16 lags 14 c .. 14 c + 15.  A cell is listed when one of its lags (centres, plus lag 0
-// for cell 0 and the last lag for the last cell) has an upper bound P32 + E_b that reaches `level`.
-// pass 0 counts the listed cells per workgroup, pass 1 writes their numbers in ascending order.
+// for cell 0 and the last lag for the last cell) has an upper bound P32 + E_b that reaches misc->lim.
+// scr_flag_kernel looks at the lags once: a workgroup covers 64 segments of 64 cells, leaves one 64-bit hit mask per
+// segment and the number of hits; after the scan of those numbers scr_scatter_kernel turns the masks into the ascending
+// list of cell numbers.  The four waves of a flag workgroup take every fourth segment and never wait for one another
+// inside the loop (a stream with a chirp every 78 000 samples has one or two active blocks, four to eight active
+// segments, under a workgroup).
 #define SCR_LIST_THREADS 256
-#define SCR_LIST_GROUPS 16           /* groups of 256 cells per workgroup: 4096 cells = 57 344 lags */
-__global__ __launch_bounds__(SCR_LIST_THREADS) void scr_cells_kernel(const float* __restrict__ P32, const float* __restrict__ blk_max,
-                                                                     const float* __restrict__ blk_err, int H, int64_t plen, int64_t ncell,
-                                                                     const ScrMisc* misc, int64_t* counts,
-                                                                     const int64_t* offsets, int64_t* cells, int64_t cap) {
+#define SCR_LIST_SEGS 64             /* segments of 64 cells per workgroup: 4096 cells = 57 344 lags */
+__global__ __launch_bounds__(SCR_LIST_THREADS) void scr_flag_kernel(const float* __restrict__ P32, const float* __restrict__ blk_max,
+                                                                    const float* __restrict__ blk_err, int H, int64_t plen, int64_t ncell,
+                                                                    const ScrMisc* misc, unsigned long long* masks, int64_t* counts) {
     __shared__ int wsum[SCR_LIST_THREADS / 64];
-    if (misc->status & 1) { if (!offsets && threadIdx.x == 0) counts[blockIdx.x] = 0; return; }
-    if (offsets && counts[blockIdx.x] == 0) return;
+    __shared__ unsigned long long blkmask;
     const double level = misc->lim;
     const bool all = !(level == level);                                      // NaN level: nothing can be excluded
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Which of the (at most 64) output blocks under this workgroup's lags can reach the level at all: one parallel
-    // look, shared through LDS.  In a stream with a chirp every 78 000 samples most workgroups leave right here.
-    __shared__ unsigned long long blkmask;
-    const int64_t b_first = (GF3_SCR_CELL * (int64_t)blockIdx.x * SCR_LIST_GROUPS * SCR_LIST_THREADS) / H;
+    // look, shared through LDS.  Most lags of a stream lie under blocks that cannot.
+    const int64_t b_first = (GF3_SCR_CELL * (int64_t)blockIdx.x * SCR_LIST_SEGS * 64) / H;
     if (wave == 0) {
         const int64_t bb = b_first + lane;
         const bool act = bb * (int64_t)H < plen && ((double)blk_max[bb] + (double)blk_err[bb] >= level);
@@ -561,18 +584,19 @@ __global__ __launch_bounds__(SCR_LIST_THREADS) void scr_cells_kernel(const float
     }
     __syncthreads();
     const unsigned long long bm = blkmask;
-    if (bm == 0) { if (!offsets && threadIdx.x == 0) counts[blockIdx.x] = 0; return; }
-    int64_t run = offsets ? offsets[blockIdx.x] : 0;                         // cells listed so far (uniform)
-    for (int g = 0; g < SCR_LIST_GROUPS; ++g) {
-        const int64_t c0 = ((int64_t)blockIdx.x * SCR_LIST_GROUPS + g) * SCR_LIST_THREADS;
+    if (bm == 0) { if (threadIdx.x == 0) counts[blockIdx.x] = 0; return; }   // (the masks are not read when the count is 0)
+    unsigned long long keep = 0;                                             // lane i: mask of segment wave + 4 i
+    for (int si = 0; si < SCR_LIST_SEGS / 4; ++si) {
+        const int seg = wave + 4 * si;
+        const int64_t c0 = ((int64_t)blockIdx.x * SCR_LIST_SEGS + seg) * 64;
         if (c0 >= ncell) break;
-        // blocks touched by this group's lags [14 c0, 14 (c0 + 256) + 2): skip the group when none can reach the level
+        // blocks touched by this segment's lags [14 c0, 14 (c0 + 64) + 2): skip it when none can reach the level
         // (32-bit arithmetic relative to the workgroup's first block: 64-bit divisions are long scalar sequences)
         const unsigned rel0 = (unsigned)(GF3_SCR_CELL * c0 - b_first * (int64_t)H);
-        const int r0 = (int)(rel0 / (unsigned)H), r1 = (int)((rel0 + GF3_SCR_CELL * SCR_LIST_THREADS + 1) / (unsigned)H);
+        const int r0 = (int)(rel0 / (unsigned)H), r1 = (int)((rel0 + GF3_SCR_CELL * 64 + 1) / (unsigned)H);
         const unsigned long long span = (r1 >= 63 ? ~0ull : ((1ull << (r1 + 1)) - 1ull)) & ~((1ull << r0) - 1ull);
-        if (!(bm & span)) continue;                                          // (uniform)
-        const int64_t c = c0 + threadIdx.x;
+        if (!(bm & span)) continue;                                          // (uniform over the wave)
+        const int64_t c = c0 + lane;
         bool hit = false;
         if (c < ncell) {
             int64_t lo = GF3_SCR_CELL * c + 1, hi = lo + GF3_SCR_CELL;       // centres [lo, hi)
@@ -602,25 +626,36 @@ __global__ __launch_bounds__(SCR_LIST_THREADS) void scr_cells_kernel(const float
             hit = hit || all;
         }
         const unsigned long long bal = __ballot(hit);
-        __syncthreads();                                                     // the previous group's wsum has been read
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, total = 0;
-        for (int w = 0; w < SCR_LIST_THREADS / 64; ++w) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
-        if (offsets && hit) {
-            const int64_t o = run + woff + __popcll(bal & ((1ull << lane) - 1ull));
-            if (o < cap) cells[o] = c;
-        }
-        run += total;
+        if (lane == si) keep = bal;
     }
-    if (!offsets && threadIdx.x == 0) counts[blockIdx.x] = run;
+    if (lane < SCR_LIST_SEGS / 4) masks[(int64_t)blockIdx.x * SCR_LIST_SEGS + wave + 4 * lane] = keep;
+    int n = __popcll(keep);
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);              // (lanes 16 .. 63 hold 0)
+    if (lane == 0) wsum[wave] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = (int64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
-
-// total of the cell list -> misc, overflow -> status
-__global__ void scr_total_kernel(const int64_t* total, int64_t cap, ScrMisc* misc) {
+// One wave per flag workgroup: segment masks + the workgroup's offset -> cell numbers in ascending order.  Workgroup 0
+// also publishes the list length and raises the overflow flag.
+__global__ __launch_bounds__(64) void scr_scatter_kernel(const unsigned long long* masks, const int64_t* counts, const int64_t* offsets,
+                                                         const int64_t* total, ScrMisc* misc, int64_t* cells, int64_t cap) {
     const long long n = total[0];
-    misc->ncell = n;
-    if (n > cap) misc->status |= 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { misc->ncell = n; if (n > cap) misc->status |= 1; }
+    if (n > cap || counts[blockIdx.x] == 0) return;
+    const int lane = threadIdx.x;
+    unsigned long long m = masks[(int64_t)blockIdx.x * SCR_LIST_SEGS + lane];
+    const int pc = __popcll(m);
+    int x = pc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    int64_t o = offsets[blockIdx.x] + (x - pc);
+    const int64_t c0 = ((int64_t)blockIdx.x * SCR_LIST_SEGS + lane) * 64;
+    while (m) {
+        const int j = __ffsll((long long)m) - 1;
+        cells[o++] = c0 + j;                                                 // (o < n <= cap)
+        m &= m - 1;
+    }
 }
 
 // fp64 re-evaluation of the 16 lags of one cell: P[m] = sum_k r[m - Lc + 1 + k] c[k], m = 14 c + j, j = 0..15.
@@ -631,8 +666,7 @@ struct RefineArgs {
     const double* chirp; int Lc;
     const int64_t* cells; ScrMisc* misc;
     int64_t plen;
-    double* cell_val;             // [ncell][16] the cell's fp64 lags
-    double* cell_max;             // [ncell] their maximum over the lags that exist (NaN if one of them is)
+    double* cell_val;             // [ncell][16] the cell's fp64 lags (their maximum goes to misc->m_key / m_nan)
 };
 #define SCR_REF_THREADS 256
 #define SCR_REF_WT 1024                              /* taps staged per wave and step: 16 per lane */
@@ -752,24 +786,13 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
             if (m0 + j < a.plen) { mx = fmax(mx, s); nan = nan || !(s == s); }
         }
         if (lane < 16) a.cell_val[cur * 16 + lane] = mine;
-        if (lane == 0) a.cell_max[cur] = nan ? NAN : mx;
+        if (lane == 0) {
+            if (nan) atomicOr(&a.misc->m_nan, 1u);
+            else if (mx > -INFINITY) atomicMax(&a.misc->m_key, scr_key(mx));
+        }
         if (nx >= ncell) break;                        // (uniform)
         cur = nx; cur_cell = nx_cell; st = 0;
     }
-}
-
-// maximum over the re-evaluated cells -> misc->M
-__global__ void scr_max_kernel(const double* cell_max, ScrMisc* misc) {
-    __shared__ double scratch[16];
-    if (misc->status & 1) return;
-    double m = -INFINITY;
-    const long long n = misc->ncell;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) m = fmax(m, cell_max[i]);
-    bool nan = false;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) nan = nan || !(cell_max[i] == cell_max[i]);
-    m = block_max(m, scratch);
-    const int anynan = __syncthreads_or(nan ? 1 : 0);
-    if (threadIdx.x == 0) misc->M = anynan ? NAN : m;                     // (np.amax propagates NaN)
 }
 
 // candidates of every listed cell: the reference's rule on the fp64 values, division by the maximum first
@@ -778,8 +801,9 @@ __global__ void scr_decide_kernel(const int64_t* cells, const double* cell_val, 
                                   unsigned* cell_mask, int64_t* cell_cnt) {
     if (misc->status & 1) return;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const double M = misc->m_nan ? NAN : scr_unkey(misc->m_key);          // (np.amax propagates NaN)
+    if (i == 0) misc->M = M;
     if (i >= misc->ncell) return;
-    const double M = misc->M;
     const int64_t m0 = GF3_SCR_CELL * cells[i];
     double p[16];
 #pragma unroll
@@ -812,7 +836,3 @@ __global__ void scr_expand_kernel(const int64_t* cells, const unsigned* cell_mas
     }
 }
 
-// a fallen-back call must not walk a candidate list that was never written
-__global__ void scr_guard_kernel(const ScrMisc* misc, int64_t* total) {
-    if (misc->status & 1) total[0] = 0;
-}
