@@ -575,7 +575,12 @@ __global__ __launch_bounds__(SCR_LIST_THREADS) void scr_flag_kernel(const float*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Which of the (at most 64) output blocks under this workgroup's lags can reach the level at all: one parallel
     // look, shared through LDS.  Most lags of a stream lie under blocks that cannot.
-    const int64_t b_first = (GF3_SCR_CELL * (int64_t)blockIdx.x * SCR_LIST_SEGS * 64) / H;
+    // (first block by a double multiplication and a correction: a 64-bit division is a hundred instructions, and most
+    //  workgroups do nothing else)
+    const int64_t L0 = GF3_SCR_CELL * (int64_t)blockIdx.x * SCR_LIST_SEGS * 64;       // < 2^53: exact as a double
+    int64_t b_first = (int64_t)((double)L0 * (1.0 / (double)H));
+    if (b_first * (int64_t)H > L0) --b_first;
+    if ((b_first + 1) * (int64_t)H <= L0) ++b_first;
     if (wave == 0) {
         const int64_t bb = b_first + lane;
         const bool act = bb * (int64_t)H < plen && ((double)blk_max[bb] + (double)blk_err[bb] >= level);
@@ -585,17 +590,22 @@ __global__ __launch_bounds__(SCR_LIST_THREADS) void scr_flag_kernel(const float*
     __syncthreads();
     const unsigned long long bm = blkmask;
     if (bm == 0) { if (threadIdx.x == 0) counts[blockIdx.x] = 0; return; }   // (the masks are not read when the count is 0)
-    unsigned long long keep = 0;                                             // lane i: mask of segment wave + 4 i
-    for (int si = 0; si < SCR_LIST_SEGS / 4; ++si) {
-        const int seg = wave + 4 * si;
-        const int64_t c0 = ((int64_t)blockIdx.x * SCR_LIST_SEGS + seg) * 64;
-        if (c0 >= ncell) break;
-        // blocks touched by this segment's lags [14 c0, 14 (c0 + 64) + 2): skip it when none can reach the level
-        // (32-bit arithmetic relative to the workgroup's first block: 64-bit divisions are long scalar sequences)
+    // Which of this wave's 16 segments touch a block that can reach the level: lane i answers for segment wave + 4 i
+    // (the blocks under its lags [14 c0, 14 (c0 + 64) + 2), 32-bit arithmetic relative to the workgroup's first block),
+    // then the wave walks the set bits only.
+    unsigned todo;
+    {
+        const int64_t c0 = ((int64_t)blockIdx.x * SCR_LIST_SEGS + wave + 4 * (lane & 15)) * 64;
         const unsigned rel0 = (unsigned)(GF3_SCR_CELL * c0 - b_first * (int64_t)H);
         const int r0 = (int)(rel0 / (unsigned)H), r1 = (int)((rel0 + GF3_SCR_CELL * 64 + 1) / (unsigned)H);
         const unsigned long long span = (r1 >= 63 ? ~0ull : ((1ull << (r1 + 1)) - 1ull)) & ~((1ull << r0) - 1ull);
-        if (!(bm & span)) continue;                                          // (uniform over the wave)
+        todo = (unsigned)(__ballot(lane < 16 && c0 < ncell && (bm & span) != 0) & 0xffffull);
+    }
+    unsigned long long keep = 0;                                             // lane i: mask of segment wave + 4 i
+    while (todo) {                                                           // (uniform over the wave)
+        const int si = __ffs((int)todo) - 1;
+        todo &= todo - 1;
+        const int64_t c0 = ((int64_t)blockIdx.x * SCR_LIST_SEGS + wave + 4 * si) * 64;
         const int64_t c = c0 + lane;
         bool hit = false;
         if (c < ncell) {
