@@ -996,6 +996,29 @@ __global__ __launch_bounds__(NMS_THREADS) void pk_nms(const int64_t* cand, const
         for (int k = threadIdx.x; k <= m; k += NMS_THREADS)
             J[0][k] = (unsigned short)(k < m ? nms_lower_bound(sv, m, sv[k] + Lc + 1) : m);
         __syncthreads();
+        {   // The usual stream: every candidate from the entry point on is followed, Lc + 1 later at the earliest, by
+            // the NEXT candidate, so the orbit is the whole rest of the chunk and all of it is written at once
+            // (the walk below emits 64 peaks per six dependent LDS reads: 14 us per chunk of 2048).
+            const int k0 = nms_lower_bound(sv, m, st[2]);
+            bool chain = true, wipe = false;
+            for (int k = k0 + threadIdx.x; k < m; k += NMS_THREADS) { chain = chain && (J[0][k] == k + 1); wipe = wipe || (sv[k] + Lc >= nz); }
+            const int64_t np = st[0], status = st[1];
+            if (__syncthreads_and(chain ? 1 : 0)) {
+                const int any_wipe = __syncthreads_or(wipe ? 1 : 0);
+                if (any_wipe) {
+                    if (threadIdx.x == 0) { st[0] = 0; st[1] = 1; }      // the except-branch wipes everything
+                } else {
+                    for (int k = k0 + threadIdx.x; k < m; k += NMS_THREADS) if (np + (k - k0) < cap) peaks[np + (k - k0)] = sv[k];
+                    if (threadIdx.x == 0 && k0 < m) {
+                        st[0] = np + (m - k0);
+                        st[1] = (np + (m - k0) > cap) ? 2 : status;
+                        st[2] = sv[m - 1] + Lc + 1;
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
+        }
         for (int t = 1; t < 6; ++t) {
             for (int k = threadIdx.x; k <= m; k += NMS_THREADS) J[t][k] = J[t - 1][J[t - 1][k]];
             __syncthreads();

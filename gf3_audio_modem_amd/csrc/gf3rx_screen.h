@@ -623,11 +623,12 @@ __global__ __launch_bounds__(SCR_LIST_THREADS) void scr_flag_kernel(const float*
             // a lag counts only if its own block can reach the level: blocks that cannot were possibly never written
             const bool a0 = all | ((double)blk_max[bb] + (double)e0 >= level);
             const bool a1 = (bend < hi) ? (all | ((double)blk_max[bb + 1] + (double)e1 >= level)) : a0;
-            // all (at most 16) lags are fetched before any is looked at: a short-circuiting loop would serialise
-            // sixteen HBM round trips
+            // all (at most 16) lags are fetched before any is looked at -- a short-circuiting loop would serialise
+            // sixteen HBM round trips -- and fetched whether or not their block was written (what an unwritten block
+            // holds is ignored below), so that these loads do not wait for the block bounds above either
             float pv[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) pv[j] = (lo + j < hi && ((lo + j >= bend) ? a1 : a0)) ? P32[lo + j] : -INFINITY;
+            for (int j = 0; j < 16; ++j) pv[j] = P32[lo + j < hi ? lo + j : hi - 1];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const double up = (double)pv[j] + (double)((lo + j >= bend) ? e1 : e0);
@@ -717,10 +718,10 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
         const int k0 = st * WT;
         const int64_t i0 = GF3_SCR_CELL * c - (a.Lc - 1) + k0;
         if (i0 >= 0 && i0 + WT + 15 <= a.n_in) {        // (uniform) the whole step lies inside the stream
-            const E* base = (const E*)a.in + i0;
+            const E* base = (const E*)a.in + i0 + lane;     // (one address per lane, the rest are immediate offsets)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) xr[q] = base[lane + 64 * q];
-            xr[16] = base[WT + (lane < 15 ? lane : 14)];
+            for (int q = 0; q < 16; ++q) xr[q] = base[64 * q];
+            xr[16] = ((const E*)a.in + i0)[WT + (lane < 15 ? lane : 14)];
         } else {
             const int64_t last_i = a.n_in - 1;
 #pragma unroll
@@ -732,8 +733,9 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
             }
         }
         if (k0 + WT <= a.Lc) {                          // (uniform)
+            const double* cl = a.chirp + k0 + lane;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) cr[q] = a.chirp[k0 + lane + 64 * q];
+            for (int q = 0; q < 16; ++q) cr[q] = cl[64 * q];
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
