@@ -2141,8 +2141,8 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
     ScrMisc* misc = (ScrMisc*)(base + w.o_smisc);
     int64_t* cnt = (int64_t*)(base + w.o_cnt);
     int64_t* offs = (int64_t*)(base + w.o_off);
-    int64_t* total = (int64_t*)(base + w.o_misc + 8);
-    int64_t* np = (int64_t*)(base + w.o_misc + 16);
+    int64_t* total = (int64_t*)&misc->total;
+    int64_t* np = (int64_t*)misc->np;
     int64_t* cand = (int64_t*)(base + w.o_cand);
     unsigned long long* segm = (unsigned long long*)(base + w.o_segm);
     int64_t* cell = (int64_t*)(base + w.o_cell);
@@ -2241,13 +2241,10 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     if (!d_corr && c->scr.ok && w.s_nblk > 0 && (c->stream_mode >= 2 || (c->stream_mode == 0 && n >= GF3_SCR_MIN_SAMPLES))) {
         int rc = sync_stream_screened(c, d_r, n, w, base, d_peaks, cap, st);
         if (rc != GF3_OK) return rc;
-        int64_t h[2] = {0, 0};
         ScrMisc hm;
-        HIPCHK(c, hipMemcpyAsync(h, np, 16, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(&hm, base + w.o_smisc, sizeof(ScrMisc), hipMemcpyDeviceToHost, st));
-        int64_t ncand = 0;
-        HIPCHK(c, hipMemcpyAsync(&ncand, total, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(&hm, base + w.o_smisc, sizeof(ScrMisc), hipMemcpyDeviceToHost, st));      // (the one read-back of the call)
         HIPCHK(c, hipStreamSynchronize(st));
+        const int64_t h[2] = {hm.np[0], hm.np[1]}, ncand = hm.total;
         c->last_info[1] = hm.ncell; c->last_info[2] = hm.nhit; c->last_info[3] = ncand;
         if (!(hm.status & 1)) {
             c->last_info[0] = 0;

@@ -517,6 +517,8 @@ struct ScrMisc {                  // device-resident scalars of one gf3_sync_str
     unsigned long long m_key;     // running maximum of the fp64 values, same encoding
     unsigned int mlo_done;        // workgroups of scr_mlo_kernel that have contributed
     unsigned int m_nan;           // a re-evaluated lag was NaN (np.amax then returns NaN)
+    long long total;              // length of the list being scanned (cells, then candidates)
+    long long np[2];              // pk_nms: peaks accepted, suppression status -- everything the host reads back is in this block
 };
 // order-preserving map double -> uint64 (every finite or infinite value maps above 0, so 0 can mean "nothing yet")
 GF3_DEV unsigned long long scr_key(double x) {
