@@ -77,10 +77,7 @@ GF3_DEV void scr_twiddle16(cf (&v)[16], cf w) {
 // In: v[r] = z[t + 256 r].  Out: Z[t + 256 m] in v[scr_perm(m)].  P, Q: two 4096-point LDS buffers; the caller
 // guarantees nobody still reads P when this starts storing into it, and may use P again after the call returns
 // (every thread has passed the barrier that follows the stores into Q).
-// T2 (optional): this thread's 15 second-pass twiddles tw2^1 .. tw2^15 in LDS (scr_ring_kernel keeps the 16 distinct
-// rows there: 15 broadcast reads instead of 14 complex products, and table-exact values).
-template <bool TAB = false>
-GF3_DEV void scr_fft4096(cf (&v)[16], cf* P, cf* Q, cf tw2, cf tw3, int t, const cf* T2 = nullptr) {
+GF3_DEV void scr_fft4096(cf (&v)[16], cf* P, cf* Q, cf tw2, cf tw3, int t) {
     scr_dft16(v);
 #pragma unroll
     for (int m = 0; m < 16; ++m) P[t * 16 + (m ^ (t & 15))] = v[scr_perm(m)];       // logical t*16 + m, XOR-swizzled
@@ -93,12 +90,7 @@ GF3_DEV void scr_fft4096(cf (&v)[16], cf* P, cf* Q, cf tw2, cf tw3, int t, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = x[r];
     }
-    if constexpr (TAB) {
-#pragma unroll
-        for (int r = 1; r < 16; ++r) v[r] = cfmul(v[r], T2[r - 1]);
-    } else {
-        scr_twiddle16(v, tw2);
-    }
+    scr_twiddle16(v, tw2);
     scr_dft16(v);
     {
         const int k = t & 15, base = (t - k) * 16 + k;
@@ -142,8 +134,8 @@ struct ScreenArgs {
 // share of the window's energy (sum of squares of the 32 samples it loaded).
 // (first part, shared with the band-limited kernel: samples -> complex transform, left in natural order in P; the
 //  caller puts a barrier between this and its reads of P)
-template <int DT, bool TAB = false>
-GF3_DEV float scr_window_fft(const ScreenArgs& a, int64_t seg, cf (&v)[16], cf* P, cf* Q, cf tw2, cf tw3, int t, const cf* T2 = nullptr) {
+template <int DT>
+GF3_DEV float scr_window_fft(const ScreenArgs& a, int64_t seg, cf (&v)[16], cf* P, cf* Q, cf tw2, cf tw3, int t) {
     typedef typename RawT<DT>::E E;
     // valid part of the window in window-relative sample numbers [lo, hi): 32-bit per-lane arithmetic from here on
     const int lo = seg >= 0 ? 0 : (seg <= -(int64_t)(2 * GF3_SCR_NC) ? 2 * GF3_SCR_NC : (int)(-seg));
@@ -171,7 +163,7 @@ GF3_DEV float scr_window_fft(const ScreenArgs& a, int64_t seg, cf (&v)[16], cf* 
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) e2 = fmaf(v[r].x, v[r].x, fmaf(v[r].y, v[r].y, e2));
-    scr_fft4096<TAB>(v, P, Q, tw2, tw3, t, T2);
+    scr_fft4096(v, P, Q, tw2, tw3, t);
     // exchange for the packed-real split: natural order into P (free: every thread is past the second barrier)
 #pragma unroll
     for (int m = 0; m < 16; ++m) P[t + 256 * m] = v[scr_perm(m)];
@@ -372,16 +364,12 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
     float* nrm = (float*)(bufB + NC);                 // [16][4] energy of window j in row j & 15, per wave
     float* red = nrm + 64;                            // [4] per-wave maximum of the finished block
     float* bc = red + 4;                              // [2] the finished block's error bound; the grid's running bound as read for it
-    cf* tab2 = (cf*)(bc + 4);                         // [16][15] second-pass twiddles: row t & 15 holds exp(-2 pi i 16 (t & 15) r / 4096), r = 1..15
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     // (XCD-aware order as in scr_ols_kernel: each XCD walks its own contiguous eighth of the stream)
     const int64_t b0 = (int64_t)a.R * xcd_order(blockIdx.x, gridDim.x);
     if (b0 >= a.nblk) return;                                          // (uniform: padding workgroups)
     const int64_t b1 = b0 + a.R < a.nblk ? b0 + a.R : a.nblk;
     cf tw2 = a.tw[(t & 15) * 16], tw3 = a.tw[t], wb = a.twn[t];
-    if (t < 240) tab2[t] = a.tw[((t / 15) * 16 * (t % 15 + 1)) & (NC - 1)];
-    const cf* T2 = tab2 + 15 * (t & 15);
-    lds_barrier();
     auto refresh = [&]() {                            // (see scr_ols_kernel: keeps the twiddle powers out of the loop-invariant set)
         asm volatile("" : "+v"(tw2.x), "+v"(tw2.y), "+v"(tw3.x), "+v"(tw3.y), "+v"(wb.x), "+v"(wb.y));
     };
@@ -401,7 +389,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
         cf v[16];
         const int64_t seg = j * (int64_t)a.H - (a.Lc - 1);
         refresh();
-        float e2 = scr_window_fft<DT, true>(a, seg, v, bufA, bufB, tw2, tw3, t, T2);
+        float e2 = scr_window_fft<DT>(a, seg, v, bufA, bufB, tw2, tw3, t);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) e2 += __shfl_xor(e2, d, 64);
         if (lane == 0) nrm[(int)(j & 15) * 4 + wave] = e2;
@@ -453,7 +441,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
             lds_barrier();
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = (r >= KS && r < 16 - KS) ? cfmk(0.0f, 0.0f) : bufB[t + 256 * r];
-            scr_fft4096<true>(v, bufA, bufB, tw2, tw3, t, T2);
+            scr_fft4096(v, bufA, bufB, tw2, tw3, t);
             // z = conj(FFT(conj Z)) / NC ; y[2n] = Re z, y[2n+1] = Im z, n = t + 256 m; the block's lags are n < H / 2 <= 2048
             const int64_t m0 = b * (int64_t)a.H;
             const int64_t left = a.plen - m0;
