@@ -107,12 +107,13 @@ def test_gpu_stream_sync_matches_oracle(N, F, cp_frac, storage, snr_db, seed):
     cfg = RxConfig(N=p.N, CP=p.CP, P=p.P, D=p.D, data_bins=p.data_carriers, const_points=p.const_points, const_bits=p.const_bits,
                    known_bits=p.known_bits, in_dtype=dt, fit_lo=p.fit_lo, fit_hi=p.fit_hi)
     eng = Engine(cfg)
-    eng.sync_stream_mode(2)                                             # screen at any length
     x = torch.from_numpy(rq).cuda()
-    got = eng.sync_stream(x).cpu().numpy()
-    info = eng.sync_stream_info()
-    assert np.array_equal(got, want), (info, got, want)
-    assert info["path"] in (0, 1)
+    for mode in (2, 3):                                                 # screen at any length: the plan's kernel, the general kernel
+        eng.sync_stream_mode(mode)
+        got = eng.sync_stream(x).cpu().numpy()
+        info = eng.sync_stream_info()
+        assert np.array_equal(got, want), (mode, info, got, want)
+        assert info["path"] in (0, 1)
     eng.sync_stream_mode(1)
     assert np.array_equal(eng.sync_stream(x).cpu().numpy(), want)
     eng.close()
