@@ -363,8 +363,9 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
     cf* bufB = bufA + NC;
     float* nrm = (float*)(bufB + NC);                 // [16][4] energy of window j in row j & 15, per wave
     float* red = nrm + 64;                            // [4] per-wave maximum of the finished block
-    float* bc = red + 4;                              // [2] the finished block's error bound; the grid's running bound as read for it
+    float* bc = red + 4;                              // [2] the finished block's error bound; the grid's running bound as read for it; [8] the partitions' error coefficients
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // (in a scalar register for the once-per-block code)
     // (XCD-aware order as in scr_ols_kernel: each XCD walks its own contiguous eighth of the stream)
     const int64_t b0 = (int64_t)a.R * xcd_order(blockIdx.x, gridDim.x);
     if (b0 >= a.nblk) return;                                          // (uniform: padding workgroups)
@@ -384,7 +385,9 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
     const float s32[8] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
                           0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f};
     const bool may_skip = a.run_lo != nullptr && a.thresh > 0.0f && a.thresh < 1.0f;
-    const float ec = lane < a.Q ? a.ecoef[lane] : 0.0f;   // this lane's coefficient of the error bound (wave 0 sums lanes 0 .. Q - 1)
+    // (the partitions' error coefficients wait in LDS, and the few per-lane values of the once-per-block code below are
+    //  recomputed there: kept in registers across the transforms they are what the allocator spills)
+    if (t < GF3_SCR_RQ) bc[2 + t] = t < a.Q ? a.ecoef[t] : 0.0f;
     for (int64_t j = b0; j < b1 + (a.Q - 1); ++j) {    // windows: block b is the sum over h of window b + h with partition h
         cf v[16];
         const int64_t seg = j * (int64_t)a.H - (a.Lc - 1);
@@ -457,11 +460,12 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
-            if (lane == 0) red[wave] = mx;
+            if (lane == 0) red[wave_s] = mx;
             if (wave == 0) {                           // error bound of block b: windows b .. b + Q - 1, one per lane
-                const float* n4 = nrm + (int)((b + lane) & 15) * 4;
+                const int ql = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 7;   // (= lane & 7, from the exec mask)
+                const float* n4 = nrm + (((int)(b & 15) + ql) & 15) * 4;
                 // (lanes from Q on look at rows that may never have been written: their term is dropped, not multiplied by 0)
-                float e = lane < a.Q ? ec * (sqrtf((n4[0] + n4[1]) + (n4[2] + n4[3])) * 1.0001f) : 0.0f;
+                float e = lane < a.Q ? bc[2 + ql] * (sqrtf((n4[0] + n4[1]) + (n4[2] + n4[3])) * 1.0001f) : 0.0f;
 #pragma unroll
                 for (int d = 8; d >= 1; d >>= 1) e += __shfl_xor(e, d, 64);
                 if (lane == 0) {
