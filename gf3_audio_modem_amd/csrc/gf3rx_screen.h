@@ -218,10 +218,12 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
         asm volatile("" : "+v"(tw2.x), "+v"(tw2.y), "+v"(tw3.x), "+v"(tw3.y), "+v"(wb.x), "+v"(wb.y));
     };
     cf acc[B][16];
-    float dc[B], ny[B];
+    // (DC and Nyquist sums of the B blocks: thread 0's business only, so they live in LDS rather than in eight registers
+    //  of every thread -- which the allocator spilled)
+    float* dcn = red + 4 * B + (B + 1);               // [B][2]
+    if (t < 2 * B) dcn[t] = 0.0f;
 #pragma unroll
     for (int g = 0; g < B; ++g) {
-        dc[g] = ny[g] = 0.0f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) acc[g][s] = cfmk(0.0f, 0.0f);
     }
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
                     acc[g][2 * r] = cf_fma_conj(v[2 * r], cfmk(hh.x, hh.y), acc[g][2 * r]);
                     acc[g][2 * r + 1] = cf_fma_conj(v[2 * r + 1], cfmk(hh.z, hh.w), acc[g][2 * r + 1]);
                 }
-                if (t == 0) { dc[g] = fmaf(z0.x, a.H0N[2 * h], dc[g]); ny[g] = fmaf(z0.y, a.H0N[2 * h + 1], ny[g]); }
+                if (t == 0) { dcn[2 * g] = fmaf(z0.x, a.H0N[2 * h], dcn[2 * g]); dcn[2 * g + 1] = fmaf(z0.y, a.H0N[2 * h + 1], dcn[2 * g + 1]); }
                 asm volatile("" ::: "memory");        // one block's eight spectrum loads in flight at a time (32 registers, not 32 B)
             }
         }
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
                 bufA[k] = cfconj(Zk);
                 if (!self) bufA[NC - k] = cfconj(Zm);
             }
-            if (t == 0) bufA[0] = cfmk(dc[g] + ny[g], -(dc[g] - ny[g]));                      // conj(E + i Op), doubled like the rest
+            if (t == 0) bufA[0] = cfmk(dcn[2 * g] + dcn[2 * g + 1], -(dcn[2 * g] - dcn[2 * g + 1]));   // conj(E + i Op), doubled like the rest
             lds_barrier();
             cf v[16];
 #pragma unroll
@@ -727,7 +729,8 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
             const E* base = (const E*)a.in + i0 + lane;     // (one address per lane, the rest are immediate offsets)
 #pragma unroll
             for (int q = 0; q < 16; ++q) xr[q] = base[64 * q];
-            xr[16] = ((const E*)a.in + i0)[WT + (lane < 15 ? lane : 14)];
+            const int l15 = launder(lane);                  // (recomputed per step: hoisted, its 64-bit form is spilled for 1-byte samples)
+            xr[16] = ((const E*)a.in + i0)[WT + (l15 < 15 ? l15 : 14)];
         } else {
             const int64_t last_i = a.n_in - 1;
 #pragma unroll

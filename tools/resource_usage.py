@@ -24,7 +24,9 @@ if __name__ == "__main__":
         txt = open(args[0]).read()
     else:
         with tempfile.TemporaryDirectory() as d:
-            cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+            sys.path.insert(0, ROOT)
+            from gf3_audio_modem_amd.build import FLAGS                      # exactly the flags the library is built with
+            cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-I" + os.path.join(ROOT, "include"),
                    "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(d, "x.so"), os.path.join(ROOT, "gf3_audio_modem_amd", "csrc", "gf3rx.hip")]
             if "--dev" in sys.argv:
                 cmd.insert(1, "-DGF3_DEV_BUILD")
