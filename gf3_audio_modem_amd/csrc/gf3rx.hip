@@ -835,6 +835,7 @@ __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
     }
     const double inv = 1.0 / (double)NC;
     double mx = -INFINITY;                            // max of the lags this workgroup writes (OFDM.py:359 needs max(P))
+    bool nan = false;
 #pragma unroll
     for (int g = 0; g < B; ++g) {
         const int64_t m0 = (b + g) * (int64_t)a.H;
@@ -868,12 +869,14 @@ __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
                 const double y0 = z.x * inv, y1 = -z.y * inv;
                 a.corr[m0 + 2 * i] = y0;
                 mx = fmax(mx, y0);
-                if (2 * i + 1 < W) { a.corr[m0 + 2 * i + 1] = y1; mx = fmax(mx, y1); }
+                nan = nan || !(y0 == y0);
+                if (2 * i + 1 < W) { a.corr[m0 + 2 * i + 1] = y1; mx = fmax(mx, y1); nan = nan || !(y1 == y1); }
             }
         }
     }
     mx = block_max(mx, (double*)lds);                 // (starts with a barrier: every wave is done reading yb)
-    if (tid == 0) a.part[item] = mx;
+    const int anynan = __syncthreads_or(nan ? 1 : 0);  // np.amax propagates NaN (OFDM.py:359): so does this maximum
+    if (tid == 0) a.part[item] = anynan ? NAN : mx;
 }
 
 // ============================================================================
@@ -885,9 +888,11 @@ __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
 __global__ void pk_max_final(const double* partial, int n, double* out) {
     __shared__ double scratch[16];
     double mx = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmax(mx, partial[i]);
+    bool nan = false;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const double v = partial[i]; mx = fmax(mx, v); nan = nan || !(v == v); }
     mx = block_max(mx, scratch);
-    if (threadIdx.x == 0) out[0] = mx;
+    const int anynan = __syncthreads_or(nan ? 1 : 0);
+    if (threadIdx.x == 0) out[0] = anynan ? NAN : mx;
 }
 // pass 0: count per block; pass 1: write ascending indices at the block's offset (blocks that counted none return
 // at once, and candidates are a handful per chirp, so the second pass costs next to nothing).
@@ -2155,7 +2160,8 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
     HIPCHK(c, hipMemsetAsync(misc, 0, sizeof(ScrMisc) + 16, st));
     {   // 1. every lag in fp32, with a bound per block
         ScreenArgs a{d_r, n, dt, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, w.s_nblk, w.plen,
-                     P32, blk_max, blk_err, (int*)(base + w.o_smisc + sizeof(ScrMisc)), (float)c->cfg.thresh, nullptr, nullptr, 0};
+                     P32, blk_max, blk_err, (int*)(base + w.o_smisc + sizeof(ScrMisc)), (float)c->cfg.thresh, nullptr, nullptr, 0,
+                     (unsigned long long*)&misc->status};
         HIPCHK(c, launch_screen(c, a, c->stream_mode == 3, st));
     }
     // 2. the cells whose lags the bounds cannot exclude, in ascending order (flag + count, scan, scatter)
@@ -2215,7 +2221,7 @@ extern "C" int gf3_debug_stream_screen(gf3_ctx* c, const void* d_r, int64_t n, f
     const int64_t plen = n + c->Lc - 1, nblk = (plen + sp.H - 1) / sp.H;
     *h_hop = sp.H;
     ScreenArgs a{d_r, n, c->cfg.in_dtype, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, nblk, plen,
-                 d_p32, d_blk, d_blk + nblk, nullptr, 0.0f, nullptr, nullptr, 0};      // (no skipping: the tests look at every lag)
+                 d_p32, d_blk, d_blk + nblk, nullptr, 0.0f, nullptr, nullptr, 0, nullptr};      // (no skipping: the tests look at every lag)
     HIPCHK(c, launch_screen(c, a, c->stream_mode == 3, (hipStream_t)stream));
     return GF3_OK;
 }

@@ -127,6 +127,8 @@ struct ScreenArgs {
     const float4* Hb;          // [Q][GF3_SCR_KS / 2][256]: (H_q[k], H_q[k + 256]), k = t + 512 p  -- the bins below 256 GF3_SCR_KS
     const float* ecoef;        // [Q] error per unit |x|_2: rounding (GF3_SCR_GAMMA max|H_q|) + the dropped bins' |h_q,out|_2
     int R;                     // output blocks per workgroup
+    unsigned long long* bad;   // optional: bit 0 is set when a window's energy is not finite in fp32 (NaN / Inf samples, or
+                               // finite ones beyond 1e19): the bounds mean nothing then and the caller takes the fp64 path
 };
 
 // one window: samples -> spectrum slots.  X[2r] = X[k_r], X[2r+1] = X[4096 - k_r], k_r = t + 256 r (thread 0, r = 0:
@@ -338,6 +340,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
                 a.blk_err[b0 + g] = be;
                 const float lo = bmax - be;
                 if (a.run_lo && lo > 0.0f && lo > run) atomicMax(a.run_lo, __float_as_int(lo));   // positive floats order like their bits; rare once a chirp has been seen
+                if (a.bad && !(be < INFINITY)) atomicOr(a.bad, 1ull);
             }
         }
     }
@@ -497,6 +500,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
                 a.blk_err[b] = be;
                 const float lo = bmax - be;
                 if (a.run_lo && lo > 0.0f && lo > run) atomicMax(a.run_lo, __float_as_int(lo));
+                if (a.bad && !(be < INFINITY)) atomicOr(a.bad, 1ull);
             }
         } else {
             lds_barrier();                             // (the next window's first stores go to bufA, which the split above reads)
