@@ -925,7 +925,7 @@ def test_stream_sync_non_finite_huge_and_tiny_samples(mode):
     nothing anywhere in the stream -- so do the all-fp64 path (a NaN-propagating maximum) and the screened paths (a
     window whose fp32 energy is not finite sends the call to the fp64 path).  The same exit serves finite samples
     beyond fp32's range, and samples so small that fp32 sees silence fall back through the empty bound: the peaks of
-    the stream scaled by 1e30 / 1e-30 are the peaks of the stream.  Inverted and negative-only streams for good measure."""
+    the stream scaled by 1e30 / 1e-45 are the peaks of the stream (1e-30 is still within fp32's reach: screened).  Inverted and negative-only streams for good measure."""
     import warnings
     g = load("g1_n1024_qpsk")
     p = params_of(g)
@@ -933,7 +933,7 @@ def test_stream_sync_non_finite_huge_and_tiny_samples(mode):
     rs = np.random.RandomState(4)
     n = 60000
     base = 0.01 * rs.randn(n); base[5000:5000 + p.Lc] += c; base[30000:30000 + p.Lc] += c
-    cases = {"nan": base.copy(), "inf": base.copy(), "ninf": base.copy(), "huge": base * 1e30, "tiny": base * 1e-30,
+    cases = {"nan": base.copy(), "inf": base.copy(), "ninf": base.copy(), "huge": base * 1e30, "small": base * 1e-30, "tiny": base * 1e-45,
              "inverted": -base, "negative_only": -np.abs(base), "neg_dc": base - 5.0, "neg_const": np.full(40000, -3.0)}
     cases["nan"][12345] = np.nan; cases["inf"][23456] = np.inf; cases["ninf"][23456] = -np.inf
     eng = engine_for(p)
@@ -946,7 +946,7 @@ def test_stream_sync_non_finite_huge_and_tiny_samples(mode):
         assert np.array_equal(got, want), (name, mode, eng.sync_stream_info(), got[:8], want[:8])
         if name in ("nan", "inf", "ninf"):
             assert len(want) == 0
-        if name in ("huge", "tiny"):
+        if name in ("huge", "small", "tiny"):
             assert len(want) == 2
         if mode >= 2 and name in ("nan", "inf", "ninf", "huge", "tiny"):
             assert eng.sync_stream_info()["path"] == 1, (name, eng.sync_stream_info())
