@@ -2124,7 +2124,7 @@ static hipError_t launch_screen(const gf3_ctx* c, ScreenArgs a, bool general, hi
         int64_t R = sp.R_forced > 0 ? sp.R_forced : (a.nblk + slots * rounds - 1) / (slots * rounds);
         if (R < 4) R = 4;
         a.Hb = sp.d_Hb; a.ecoef = sp.d_ecoef; a.R = (int)R;
-        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (64 + 4 + 2 + GF3_SCR_RQ + 2) * sizeof(float);
+        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (64 + 8 + 2 + GF3_SCR_RQ + 2) * sizeof(float);
         const int64_t grid = (((a.nblk + R - 1) / R + 7) / 8) * 8;                        // padded to the 8 XCDs (xcd_order)
         DISPATCH_DT(a.dt, e = launch((scr_ring_kernel<DTC>), grid, GF3_SCR_T, lds, st, a));
     } else {

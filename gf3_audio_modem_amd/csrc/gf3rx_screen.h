@@ -367,8 +367,8 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
     cf* bufA = (cf*)smem;
     cf* bufB = bufA + NC;
     float* nrm = (float*)(bufB + NC);                 // [16][4] energy of window j in row j & 15, per wave
-    float* red = nrm + 64;                            // [4] per-wave maximum of the finished block
-    float* bc = red + 4;                              // [2] the finished block's error bound; the grid's running bound as read for it; [8] the partitions' error coefficients
+    float* red = nrm + 64;                            // [4] per-wave maximum of the finished block, [4] per-wave l1 norm of its spectrum
+    float* bc = red + 8;                              // [2] the finished block's error bound; the grid's running bound as read for it; [8] the partitions' error coefficients
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // (in a scalar register for the once-per-block code)
     // (XCD-aware order as in scr_ols_kernel: each XCD walks its own contiguous eighth of the stream)
@@ -430,6 +430,45 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
         }
         const int64_t b = j - (a.Q - 1);               // the block this window completes
         if (b >= b0) {                                 // (uniform; the first Q - 1 windows only fill the ring)
+            // ---- Can the block matter at all?  |y[i]| <= (1/N) sum_k |Y_k| over the two-sided spectrum: the l1 norm of the
+            // kept half, before any inverse transform.  A chirp partition lives in its own sixth of the band, so the
+            // products of a window with the partitions it is NOT aligned with are small in every bin: off the two or
+            // three blocks around a chirp's peak this bound is 4-7 % of the peak, well under the threshold, and the
+            // inverse transform (40 % of the kernel's arithmetic) is not run for 17 of 20 blocks of a config-3 packet.
+            {
+                float s1 = 0.0f;
+#pragma unroll
+                for (int r = 0; r < KS; ++r) s1 += sqrtf(fmaf(acc[0][r].x, acc[0][r].x, acc[0][r].y * acc[0][r].y));
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) s1 += __shfl_xor(s1, d, 64);
+                if (lane == 0) red[4 + wave_s] = s1;
+            }
+            if (wave == 0) {                           // error bound of block b: windows b .. b + Q - 1, one per lane
+                const int ql = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 7;   // (= lane & 7, from the exec mask)
+                const float* n4 = nrm + (((int)(b & 15) + ql) & 15) * 4;
+                // (lanes from Q on look at rows that may never have been written: their term is dropped, not multiplied by 0)
+                float e = lane < a.Q ? bc[2 + ql] * (sqrtf((n4[0] + n4[1]) + (n4[2] + n4[3])) * 1.0001f) : 0.0f;
+#pragma unroll
+                for (int d = 8; d >= 1; d >>= 1) e += __shfl_xor(e, d, 64);
+                if (lane == 0) {
+                    bc[0] = e * 1.0001f + 1e-37f;
+                    // (one lane reads the shared bound -- 256 lanes hammering one address would serialise the whole grid)
+                    bc[1] = may_skip ? __int_as_float(__atomic_load_n(a.run_lo, __ATOMIC_RELAXED)) : 0.0f;
+                }
+            }
+            lds_barrier();                             // (also: every thread is done with the split's reads of bufA)
+            const float be = bc[0], run = bc[1];
+            // acc holds 2 Y_k (the split's doubling), k >= 0 only: (1/8192) (|Y_0| + 2 sum_{k>0} |Y_k|) <= (1/8192) sum |acc_k|
+            const float l1 = ((red[4] + red[5]) + (red[6] + red[7])) * (1.0001f / 8192.0f);
+            // (same rule as for the stores below: under thresh x an established lower bound of the maximum a block can hold
+            //  neither the maximum nor a candidate, whatever the final maximum turns out to be)
+            if (may_skip && run > 0.0f && (l1 + be) < a.thresh * run * (1.0f - 1e-6f) * 0.9999f) {     // (uniform)
+                if (t == 0) {
+                    a.blk_max[b] = -INFINITY;           // never listed, no part in the lower bound of the maximum
+                    a.blk_err[b] = be;
+                    if (a.bad && !(be < INFINITY)) atomicOr(a.bad, 1ull);
+                }
+            } else {
             // ---- inverse real FFT of the Hermitian spectrum whose kept half is acc[0]; every other bin is zero
             refresh();
 #pragma unroll
@@ -466,22 +505,8 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
             if (lane == 0) red[wave_s] = mx;
-            if (wave == 0) {                           // error bound of block b: windows b .. b + Q - 1, one per lane
-                const int ql = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 7;   // (= lane & 7, from the exec mask)
-                const float* n4 = nrm + (((int)(b & 15) + ql) & 15) * 4;
-                // (lanes from Q on look at rows that may never have been written: their term is dropped, not multiplied by 0)
-                float e = lane < a.Q ? bc[2 + ql] * (sqrtf((n4[0] + n4[1]) + (n4[2] + n4[3])) * 1.0001f) : 0.0f;
-#pragma unroll
-                for (int d = 8; d >= 1; d >>= 1) e += __shfl_xor(e, d, 64);
-                if (lane == 0) {
-                    bc[0] = e * 1.0001f + 1e-37f;
-                    // (one lane reads the shared bound -- 256 lanes hammering one address would serialise the whole grid)
-                    bc[1] = may_skip ? __int_as_float(__atomic_load_n(a.run_lo, __ATOMIC_RELAXED)) : 0.0f;
-                }
-            }
             lds_barrier();
             const float bmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-            const float be = bc[0], run = bc[1];
             // (same rule as scr_ols_kernel: a block whose upper bound stays below thresh x an established lower bound
             //  of the maximum can hold neither the maximum nor a candidate; its lags are never read again)
             const bool skip = may_skip && run > 0.0f && (bmax + be) < a.thresh * run * (1.0f - 1e-6f) * 0.9999f;
@@ -501,6 +526,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
                 const float lo = bmax - be;
                 if (a.run_lo && lo > 0.0f && lo > run) atomicMax(a.run_lo, __float_as_int(lo));
                 if (a.bad && !(be < INFINITY)) atomicOr(a.bad, 1ull);
+            }
             }
         } else {
             lds_barrier();                             // (the next window's first stores go to bufA, which the split above reads)
