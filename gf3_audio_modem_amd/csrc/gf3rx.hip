@@ -1536,7 +1536,7 @@ static int build_screen_plan(gf3_ctx* c) {
     // band-limited kernel: the kept bins in its slot order, and per partition the error per unit |x|_2 -- rounding
     // (GF3_SCR_GAMMA max|H_q|) plus the 2-norm of what the dropped bins |k| >= 256 KS hold (gf3rx_screen.h)
     constexpr int KS = GF3_SCR_KS;
-    std::vector<float> Hb((size_t)Q * (KS / 2) * T * 4), ecoef(Q);
+    std::vector<float> Hb((size_t)Q * (KS / 2) * T * 4), ecoef(2 * (size_t)Q);
     double hout_sum = 0.0, hall_sum = 0.0;
     for (int q = 0; q < Q; ++q) {
         std::vector<double> re(N, 0.0), im(N, 0.0);
@@ -1562,7 +1562,8 @@ static int build_screen_plan(gf3_ctx* c) {
         for (int k = 256 * KS; k < NC; ++k) out2 += 2.0 * (re[k] * re[k] + im[k] * im[k]);
         for (int k = 0; k < N; ++k) all2 += re[k] * re[k] + im[k] * im[k];
         const double hout = sqrt(out2 / N) * (1.0 + 1e-9);
-        ecoef[q] = (float)(((double)GF3_SCR_GAMMA * Hinf[q] + hout) * (1.0 + 1e-6));
+        ecoef[q] = (float)((double)GF3_SCR_GAMMA * ((double)Hinf[q] + hout) * (1.0 + 1e-6));     // per unit |x|_2
+        ecoef[Q + q] = (float)(hout * (1.0 + 1e-6));                                             // per unit |x_out|_2
         hout_sum += hout; hall_sum += sqrt(all2 / N);
     }
     // (selective only when the chirp lives below the cut: the reference's 0-8 kHz sweep at 48 kHz drops ~1.3 %)
@@ -2124,7 +2125,7 @@ static hipError_t launch_screen(const gf3_ctx* c, ScreenArgs a, bool general, hi
         int64_t R = sp.R_forced > 0 ? sp.R_forced : (a.nblk + slots * rounds - 1) / (slots * rounds);
         if (R < 4) R = 4;
         a.Hb = sp.d_Hb; a.ecoef = sp.d_ecoef; a.R = (int)R;
-        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (64 + 8 + 2 + GF3_SCR_RQ + 2) * sizeof(float);
+        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (64 + 64 + 8 + 2 + 2 * GF3_SCR_RQ + 2) * sizeof(float);
         const int64_t grid = (((a.nblk + R - 1) / R + 7) / 8) * 8;                        // padded to the 8 XCDs (xcd_order)
         DISPATCH_DT(a.dt, e = launch((scr_ring_kernel<DTC>), grid, GF3_SCR_T, lds, st, a));
     } else {

@@ -125,7 +125,7 @@ struct ScreenArgs {
     float thresh;              // 0 < thresh < 1 enables skipping the store of blocks that cannot matter
     // band-limited kernel (scr_ring_kernel) only:
     const float4* Hb;          // [Q][GF3_SCR_KS / 2][256]: (H_q[k], H_q[k + 256]), k = t + 512 p  -- the bins below 256 GF3_SCR_KS
-    const float* ecoef;        // [Q] error per unit |x|_2: rounding (GF3_SCR_GAMMA max|H_q|) + the dropped bins' |h_q,out|_2
+    const float* ecoef;        // [2][Q] error per unit |x|_2: GF3_SCR_GAMMA (max|H_q| + |h_q,out|_2); per unit |x_out|_2: |h_q,out|_2
     int R;                     // output blocks per workgroup
     unsigned long long* bad;   // optional: bit 0 is set when a window's energy is not finite in fp32 (NaN / Inf samples, or
                                // finite ones beyond 1e19): the bounds mean nothing then and the caller takes the fp64 path
@@ -350,10 +350,13 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
 // The reference's chirp sweeps 0 .. 8 kHz at fs = 48 kHz (OFDM.py:106-109): above bin 8192 * 8000 / 48000 = 1365 of an
 // 8192-sample window the partitions' spectra hold about 1 % of their energy (the tails of the segment edges).
 // Leaving the bins |k| >= 256 KS = 1536 out of the products changes a lag of one (window, partition) term by at most
-//     |y_drop|_inf <= (1/N) sum_dropped |X[k]| |H_q[k]| <= |x|_2 |h_q,out|_2,   |h_q,out|_2^2 = (1/N) sum_dropped |H_q[k]|^2
-// (Cauchy-Schwarz, then Parseval for both factors; the host evaluates |h_q,out|_2 in fp64 and rounds up), which joins
-// the rounding term in the block's error bound: nothing else in the method changes, the bound stays rigorous and the
-// decisions stay fp64.  What it buys: a block's accumulator is KS = 6 complex registers per thread instead of 16, so a
+//     |y_drop|_inf <= (1/N) sum_dropped |X[k]| |H_q[k]| <= |x_out|_2 |h_q,out|_2,   |.._out|_2^2 = (1/N) sum_dropped |..[k]|^2
+// (Cauchy-Schwarz; the host evaluates |h_q,out|_2 in fp64 and rounds up; |x_out|_2, the 2-norm of the window's own
+// dropped part, is summed in the kernel from the transform it has just computed -- the computed spectrum is within
+// GF3_SCR_GAMMA |x|_2 of the true one, which is added), and this joins the rounding term in the block's error bound:
+//     E_b = sum_q [ GAMMA (max|H_q| + |h_q,out|_2) |x_{b+q}|_2  +  |h_q,out|_2 |x_{b+q},out|_2 ].
+// Next to a chirp the window is nearly all in-band and the second term is as small as the first.  Nothing else in the
+// method changes, the bound stays rigorous and the decisions stay fp64.  What it buys: a block's accumulator is KS = 6 complex registers per thread instead of 16, so a
 // RING of up to RQ = 8 unfinished blocks fits in registers and a workgroup walks R consecutive blocks with ONE forward
 // transform per window -- 2 + (Q - 1) / R transforms per block where scr_ols_kernel, which has to re-transform the
 // Q + B - 1 windows under its B = 4 blocks, needs 3.25 (Q = 6) -- and 6 instead of 16 multiply-adds per partition.
@@ -367,8 +370,9 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
     cf* bufA = (cf*)smem;
     cf* bufB = bufA + NC;
     float* nrm = (float*)(bufB + NC);                 // [16][4] energy of window j in row j & 15, per wave
-    float* red = nrm + 64;                            // [4] per-wave maximum of the finished block, [4] per-wave l1 norm of its spectrum
-    float* bc = red + 8;                              // [2] the finished block's error bound; the grid's running bound as read for it; [8] the partitions' error coefficients
+    float* nro = nrm + 64;                            // [16][4] the same for the part of its spectrum that is dropped
+    float* red = nro + 64;                            // [4] per-wave maximum of the finished block, [4] per-wave l1 norm of its spectrum
+    float* bc = red + 8;                              // [2] the finished block's error bound; the grid's running bound as read for it; [8] + [8] the partitions' error coefficients
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // (in a scalar register for the once-per-block code)
     // (XCD-aware order as in scr_ols_kernel: each XCD walks its own contiguous eighth of the stream)
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
     const bool may_skip = a.run_lo != nullptr && a.thresh > 0.0f && a.thresh < 1.0f;
     // (the partitions' error coefficients wait in LDS, and the few per-lane values of the once-per-block code below are
     //  recomputed there: kept in registers across the transforms they are what the allocator spills)
-    if (t < GF3_SCR_RQ) bc[2 + t] = t < a.Q ? a.ecoef[t] : 0.0f;
+    if (t < 2 * GF3_SCR_RQ) bc[2 + t] = (t & 7) < a.Q ? a.ecoef[(t >> 3) * a.Q + (t & 7)] : 0.0f;
     for (int64_t j = b0; j < b1 + (a.Q - 1); ++j) {    // windows: block b is the sum over h of window b + h with partition h
         cf v[16];
         const int64_t seg = j * (int64_t)a.H - (a.Lc - 1);
@@ -401,6 +405,14 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) e2 += __shfl_xor(e2, d, 64);
         if (lane == 0) nrm[(int)(j & 15) * 4 + wave] = e2;
+        // Energy of the DROPPED part of this window's spectrum (what the truncation term of the bound multiplies: next
+        // to a chirp the window is nearly all in-band and this is 1e-3 of its energy).  One-sided bins 1536 .. 4096:
+        // the pairs (k, 4096 - k), 1536 <= k <= 2048, as |Z_k|^2 + |Z_{4096-k}|^2 straight from the packed transform
+        // (indices 1536 .. 2560: this thread's outputs 6 .. 9, and output 10 of thread 0) ...
+        float eo = 0.0f;
+#pragma unroll
+        for (int m = 6; m < 10; ++m) { const cf z = v[scr_perm(m)]; eo = fmaf(z.x, z.x, fmaf(z.y, z.y, eo)); }
+        { const cf z = v[scr_perm(10)]; const float g = t == 0 ? 1.0f : 0.0f; eo = fmaf(g * z.x, z.x, fmaf(g * z.y, z.y, eo)); }
         lds_barrier();
         // packed-real split, kept bins only: X[r] = 2 X[t + 256 r]  (k = 0 pairs with itself: its slot is 2 X[0], real)
         cf X[KS];
@@ -410,8 +422,14 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
             const cf A = bufA[k], Bc = cfconj(bufA[(NC - k) & (NC - 1)]);
             const cf w = cfmul(wb, cfmk(c32[r], -s32[r]));                // exp(-2 pi i k / 8192)
             const cf Ee = cfadd(A, Bc), Dd = cfsub(A, Bc);
-            X[r] = cfadd(Ee, cfmul(cf_negi(Dd), w));
+            const cf Ow = cfmul(cf_negi(Dd), w);
+            X[r] = cfadd(Ee, Ow);
+            const cf Pn = cfsub(Ee, Ow);               // ... and the partners 4096 - k of the kept bins (k = 0: the Nyquist bin), doubled like X
+            eo = fmaf(0.25f * Pn.x, Pn.x, fmaf(0.25f * Pn.y, Pn.y, eo));
         }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) eo += __shfl_xor(eo, d, 64);
+        if (lane == 0) nro[(int)(j & 15) * 4 + wave] = eo;
 #pragma unroll
         for (int i = 0; i < RQ; ++i) {
             int h = a.Q - 1 - i;                       // ring slot i holds block j - h
@@ -446,8 +464,12 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
             if (wave == 0) {                           // error bound of block b: windows b .. b + Q - 1, one per lane
                 const int ql = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 7;   // (= lane & 7, from the exec mask)
                 const float* n4 = nrm + (((int)(b & 15) + ql) & 15) * 4;
+                const float* o4 = n4 + 64;
+                // |x|_2 of the window, and of its dropped part: |x_out|_2^2 <= (2 / 8192) x the one-sided sum
+                const float nx = sqrtf((n4[0] + n4[1]) + (n4[2] + n4[3])) * 1.0001f;
+                const float no = sqrtf(((o4[0] + o4[1]) + (o4[2] + o4[3])) * (1.0f / 4096.0f)) * 1.0001f;
                 // (lanes from Q on look at rows that may never have been written: their term is dropped, not multiplied by 0)
-                float e = lane < a.Q ? bc[2 + ql] * (sqrtf((n4[0] + n4[1]) + (n4[2] + n4[3])) * 1.0001f) : 0.0f;
+                float e = lane < a.Q ? fmaf(bc[2 + ql], nx, bc[10 + ql] * no) : 0.0f;
 #pragma unroll
                 for (int d = 8; d >= 1; d >>= 1) e += __shfl_xor(e, d, 64);
                 if (lane == 0) {
@@ -471,10 +493,11 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
             } else {
             // ---- inverse real FFT of the Hermitian spectrum whose kept half is acc[0]; every other bin is zero
             refresh();
+            const int ti = launder(t);                 // (LDS addresses of this block-rate code are recomputed, not kept across the transforms)
 #pragma unroll
             for (int r = 0; r < KS; ++r) {
-                const int k = t + 256 * r;
-                const bool dc = (r == 0 && t == 0);
+                const int k = ti + 256 * r;
+                const bool dc = (r == 0 && ti == 0);
                 const cf w = cfmul(wb, cfmk(c32[r], -s32[r]));
                 const cf A = acc[0][r];
                 const cf Op = cfmul(A, cfconj(w));                          // * exp(+2 pi i k / 8192)
