@@ -402,9 +402,6 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
         const int64_t seg = j * (int64_t)a.H - (a.Lc - 1);
         refresh();
         float e2 = scr_window_fft<DT>(a, seg, v, bufA, bufB, tw2, tw3, t);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) e2 += __shfl_xor(e2, d, 64);
-        if (lane == 0) nrm[(int)(j & 15) * 4 + wave] = e2;
         // Energy of the DROPPED part of this window's spectrum (what the truncation term of the bound multiplies: next
         // to a chirp the window is nearly all in-band and this is 1e-3 of its energy).  One-sided bins 1536 .. 4096:
         // the pairs (k, 4096 - k), 1536 <= k <= 2048, as |Z_k|^2 + |Z_{4096-k}|^2 straight from the packed transform
@@ -428,8 +425,8 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
             eo = fmaf(0.25f * Pn.x, Pn.x, fmaf(0.25f * Pn.y, Pn.y, eo));
         }
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) eo += __shfl_xor(eo, d, 64);
-        if (lane == 0) nro[(int)(j & 15) * 4 + wave] = eo;
+        for (int d = 32; d >= 1; d >>= 1) { e2 += __shfl_xor(e2, d, 64); eo += __shfl_xor(eo, d, 64); }    // (two chains side by side)
+        if (lane == 0) { nrm[(int)(j & 15) * 4 + wave] = e2; nro[(int)(j & 15) * 4 + wave] = eo; }
 #pragma unroll
         for (int i = 0; i < RQ; ++i) {
             int h = a.Q - 1 - i;                       // ring slot i holds block j - h
