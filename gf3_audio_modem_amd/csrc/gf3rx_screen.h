@@ -32,6 +32,10 @@ typedef float2 cf;
 #define GF3_SCR_B 4                  /* adjacent output blocks per workgroup (share their windows' transforms) */
 #define GF3_SCR_CELL 14              /* centre lags per refinement cell (16 fp64 values with the two neighbours) */
 #define GF3_SCR_GAMMA (256.0f * 5.9604645e-8f)
+// Samples below 1e-19 have squares that underflow in fp32: a sum of 8192 rounded squares can miss 8192 x 1.4e-45 of
+// the true energy.  Added under the root, the energy stays an UPPER bound of |x|_2^2 whatever the samples' size (a stream
+// that small then has bounds far above its own correlation, lists everything and takes the fp64 path).
+#define GF3_SCR_UFLOW 2e-41f
 
 GF3_DEV cf cfmk(float a, float b) { return make_float2(a, b); }
 GF3_DEV cf cfadd(cf a, cf b) { return cfmk(a.x + b.x, a.y + b.y); }
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
         for (int q = 0; q < a.Q; ++q) {
             const float* n4 = nrm + (t + q) * 4;
             const float n2 = (n4[0] + n4[1]) + (n4[2] + n4[3]);
-            e = fmaf(a.Hinf[q], sqrtf(n2) * 1.0001f, e);
+            e = fmaf(a.Hinf[q], sqrtf(n2 + GF3_SCR_UFLOW) * 1.0001f, e);
         }
         berr[t] = e * GF3_SCR_GAMMA * 1.0001f + 1e-37f;
     }
@@ -463,8 +467,8 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
                 const float* n4 = nrm + (((int)(b & 15) + ql) & 15) * 4;
                 const float* o4 = n4 + 64;
                 // |x|_2 of the window, and of its dropped part: |x_out|_2^2 <= (2 / 8192) x the one-sided sum
-                const float nx = sqrtf((n4[0] + n4[1]) + (n4[2] + n4[3])) * 1.0001f;
-                const float no = sqrtf(((o4[0] + o4[1]) + (o4[2] + o4[3])) * (1.0f / 4096.0f)) * 1.0001f;
+                const float nx = sqrtf((n4[0] + n4[1]) + (n4[2] + n4[3]) + GF3_SCR_UFLOW) * 1.0001f;
+                const float no = sqrtf(((o4[0] + o4[1]) + (o4[2] + o4[3])) * (1.0f / 4096.0f) + GF3_SCR_UFLOW) * 1.0001f;
                 // (lanes from Q on look at rows that may never have been written: their term is dropped, not multiplied by 0)
                 float e = lane < a.Q ? fmaf(bc[2 + ql], nx, bc[10 + ql] * no) : 0.0f;
 #pragma unroll
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
             lds_barrier();                             // (also: every thread is done with the split's reads of bufA)
             const float be = bc[0], run = bc[1];
             // acc holds 2 Y_k (the split's doubling), k >= 0 only: (1/8192) (|Y_0| + 2 sum_{k>0} |Y_k|) <= (1/8192) sum |acc_k|
-            const float l1 = ((red[4] + red[5]) + (red[6] + red[7])) * (1.0001f / 8192.0f);
+            const float l1 = ((red[4] + red[5]) + (red[6] + red[7])) * (1.0001f / 8192.0f) + 5e-20f;   // (+: moduli whose squares underflowed, 1536 x 1.1e-19 at most)
             // (same rule as for the stores below: under thresh x an established lower bound of the maximum a block can hold
             //  neither the maximum nor a candidate, whatever the final maximum turns out to be)
             if (may_skip && run > 0.0f && (l1 + be) < a.thresh * run * (1.0f - 1e-6f) * 0.9999f) {     // (uniform)

@@ -761,8 +761,9 @@ def test_stream_screen_error_bound_holds(case, kernel):
     """The fp32 screening pass of gf3_sync_stream (gf3rx_screen.h) against the oracle's fp64 matched filter: on every
     lag |P32 - P| must stay below the block's bound E_b -- that is what makes the screen safe.  Both kernels: the
     general one (stream mode 3; its bound is rounding only, 256 u per partition, and the arithmetic delivers a few u)
-    and the band-limited one (default where the plan allows it: the bound also carries the 2-norm of the chirp
-    partitions' dropped bins, which a stream with all its energy in one sample comes within a factor 2 of)."""
+    and the band-limited one (default where the plan allows it: the bound also carries the product of the 2-norms of
+    what the window and the chirp partition hold in the dropped bins -- Cauchy-Schwarz, which a stream with all its
+    energy in one sample comes within 30 % of)."""
     name, p, r, dt = _screen_cases()[case]
     eng = engine_for(p, in_dtype=dt)
     eng.sync_stream_mode(3 if kernel == "general" else 2)
@@ -778,7 +779,7 @@ def test_stream_screen_error_bound_holds(case, kernel):
     assert (err <= per_lag).all(), (name, float((err / per_lag).max()))
     ratio = float((err / np.maximum(per_lag, 1e-300)).max())
     print(f"screen bound {name} ({kernel}): realised / bound = {ratio:.4f}, largest bound / max |P| = {berr.max() / np.abs(P).max():.2e}")
-    assert ratio < (0.125 if kernel == "general" else 0.75), (name, ratio)
+    assert ratio < (0.125 if kernel == "general" else 0.95), (name, ratio)
     nb = len(berr)
     want_max = np.array([p32[b * hop: (b + 1) * hop].max() for b in range(nb)])
     assert np.array_equal(bmax.astype(np.float64), want_max)
