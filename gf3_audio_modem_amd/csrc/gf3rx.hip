@@ -1527,7 +1527,10 @@ static int build_screen_plan(gf3_ctx* c) {
     auto& sp = c->scr;
     sp.ok = false;
     const int Q = (c->Lc + NC - 1) / NC;
-    int H = (c->Lc + Q - 1) / Q;
+    // hop = partition length: the full 4096 whenever the chirp needs more than one partition (the last one is short) --
+    // every sample is then transformed exactly twice and the blocks are as few as they can be (config 3: 78 342
+    // instead of 83 565 with six equal partitions of 3 840)
+    int H = Q > 1 ? NC : c->Lc;
     H += H & 1;                                          // even: the kernel stores lag pairs
     if (Q > 16 || H > NC || H < 1024) return GF3_OK;      // (outside the plan's range: fp64 path only; scr_cells_kernel's block mask
                                                         //  assumes at most 64 blocks under one workgroup's 57 346 lags)

@@ -405,6 +405,11 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
         cf v[16];
         const int64_t seg = j * (int64_t)a.H - (a.Lc - 1);
         refresh();
+        // (the grid's running bound is fetched here and used after the transform: any earlier value of a lower bound is
+        //  a lower bound, and a load issued where it is needed would hold every wave at the barrier for a round trip to
+        //  memory.  One lane reads it -- 256 lanes hammering one address would serialise the whole grid)
+        float run_pre = 0.0f;
+        if (may_skip && t == 0) run_pre = __int_as_float(__atomic_load_n(a.run_lo, __ATOMIC_RELAXED));
         float e2 = scr_window_fft<DT>(a, seg, v, bufA, bufB, tw2, tw3, t);
         // Energy of the DROPPED part of this window's spectrum (what the truncation term of the bound multiplies: next
         // to a chirp the window is nearly all in-band and this is 1e-3 of its energy).  One-sided bins 1536 .. 4096:
@@ -473,11 +478,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
                 float e = lane < a.Q ? fmaf(bc[2 + ql], nx, bc[10 + ql] * no) : 0.0f;
 #pragma unroll
                 for (int d = 8; d >= 1; d >>= 1) e += __shfl_xor(e, d, 64);
-                if (lane == 0) {
-                    bc[0] = e * 1.0001f + 1e-37f;
-                    // (one lane reads the shared bound -- 256 lanes hammering one address would serialise the whole grid)
-                    bc[1] = may_skip ? __int_as_float(__atomic_load_n(a.run_lo, __ATOMIC_RELAXED)) : 0.0f;
-                }
+                if (lane == 0) { bc[0] = e * 1.0001f + 1e-37f; bc[1] = run_pre; }
             }
             lds_barrier();                             // (also: every thread is done with the split's reads of bufA)
             const float be = bc[0], run = bc[1];
