@@ -2117,8 +2117,9 @@ extern "C" int64_t gf3_sync_stream_workspace_bytes(const gf3_ctx* c, int64_t n) 
 
 // The screening pass: the band-limited ring kernel when the plan allows it (and `general` is not asked for), else
 // the general kernel.  R, the ring kernel's blocks per workgroup: every workgroup transforms Q - 1 windows without
-// finishing a block, so R is as large as leaves a whole number of rounds of 2 workgroups per CU (config-3 stream,
-// 83 582 blocks: R = 164 -> 510 workgroups 1.71 ms, R = 82 1.72, R = 32 2.0, and 2.2 at R = 110 = 1.5 rounds).
+// finishing a block, so R is as large as leaves a whole number of rounds of 2 workgroups per CU (swept on the
+// config-3 stream when it was 83 582 blocks and every block ran its inverse transform: R = 164 -> 510 workgroups
+// 1.71 ms, R = 82 1.72, R = 32 2.0, and 2.2 at R = 110 = 1.5 rounds).
 static hipError_t launch_screen(const gf3_ctx* c, ScreenArgs a, bool general, hipStream_t st) {
     const auto& sp = c->scr;
     hipError_t e = hipSuccess;
