@@ -953,6 +953,32 @@ def test_stream_sync_non_finite_huge_and_tiny_samples(mode):
             assert eng.sync_stream_info()["path"] == 1, (name, eng.sync_stream_info())
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_stream_sync_with_interferers(mode):
+    """Chirps under a loud tone outside the chirp's band (20 kHz: everything the band-limited screen drops), under one
+    inside it (1 kHz), under both, and under white noise as loud as the chirp: the bounds grow with what the windows hold
+    outside the band, more cells are re-evaluated or the call falls back -- the peaks are the oracle's on every path."""
+    g = load("g1_n1024_qpsk")
+    p = params_of(g)
+    c = orc.chirp_replica(p)
+    rs = np.random.RandomState(12)
+    n = 90000
+    t = np.arange(n)
+    base = np.zeros(n)
+    for pos in (4000, 31000, 64000):
+        base[pos: pos + p.Lc] += c
+    cases = {"tone_out": base + 5.0 * np.sin(2 * np.pi * 20000 / 48000 * t), "tone_in": base + 1.0 * np.sin(2 * np.pi * 1000 / 48000 * t + 0.3),
+             "both": base + 3.0 * np.sin(2 * np.pi * 20000 / 48000 * t) + 0.5 * np.sin(2 * np.pi * 3000 / 48000 * t),
+             "noise": base + 0.15 * rs.randn(n), "impulses": base + 40.0 * (rs.rand(n) < 2e-4)}
+    eng = engine_for(p)
+    eng.sync_stream_mode(mode)
+    for name, r in cases.items():
+        want = np.flatnonzero(orc.chirp_method(r, p))
+        got = eng.sync_stream(torch.from_numpy(r).cuda(), cap=len(r) + p.Lc).cpu().numpy()
+        assert np.array_equal(got, want), (name, mode, eng.sync_stream_info(), got[:8], want[:8])
+        assert len(want) >= 1, name
+
+
 def test_new_abi_error_paths():
     """gf3_sync_stream_mode / gf3_equalise_known_h reject what the header says they reject."""
     g = load("g1_n1024_qpsk")
