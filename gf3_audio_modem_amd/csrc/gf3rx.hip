@@ -2133,7 +2133,7 @@ static hipError_t launch_screen(const gf3_ctx* c, ScreenArgs a, bool general, hi
         const int64_t grid = (((a.nblk + R - 1) / R + 7) / 8) * 8;                        // padded to the 8 XCDs (xcd_order)
         DISPATCH_DT(a.dt, e = launch((scr_ring_kernel<DTC>), grid, GF3_SCR_T, lds, st, a));
     } else {
-        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 7 * GF3_SCR_B + 4) * sizeof(float);
+        const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 11 * GF3_SCR_B + 4) * sizeof(float);
         const int64_t grid = (((a.nblk + GF3_SCR_B - 1) / GF3_SCR_B + 7) / 8) * 8;
         DISPATCH_DT(a.dt, e = launch((scr_ols_kernel<DTC>), grid, GF3_SCR_T, lds, st, a));
     }

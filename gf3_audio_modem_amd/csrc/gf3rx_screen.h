@@ -261,8 +261,23 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
         }
     }
     // ---- per block: error bound, inverse real FFT of the Hermitian spectrum, maximum, store
-    float* berr = red + 4 * B;                        // [B] the blocks' error bounds, [B]: the grid's running bound as read for the current block
+    float* berr = red + 4 * B;                        // [B] the blocks' error bounds, [B]: the grid's running bound
+    float* l1p = dcn + 2 * B;                         // [B][4] per-wave l1 norms of the blocks' accumulated spectra
+    // |y[i]| <= (1/N) sum_k |Y_k|, before any inverse transform (see scr_ring_kernel): the slots hold 2 Y_k for the
+    // one-sided bins 1 .. 4095 (thread 0's first pair holds bin 2048 twice: an over-estimate), thread 0 adds DC and Nyquist
+#pragma unroll
+    for (int g = 0; g < B; ++g) {
+        float s1 = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) s1 += sqrtf(fmaf(acc[g][s].x, acc[g][s].x, acc[g][s].y * acc[g][s].y));
+        if (t == 0) s1 += fabsf(dcn[2 * g]) + fabsf(dcn[2 * g + 1]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s1 += __shfl_xor(s1, d, 64);
+        if ((t & 63) == 0) l1p[g * 4 + wave] = s1;
+    }
+    const bool may_skip = a.run_lo != nullptr && a.thresh > 0.0f && a.thresh < 1.0f;
     lds_barrier();
+    if (t == 0) berr[B] = may_skip ? __int_as_float(__atomic_load_n(a.run_lo, __ATOMIC_RELAXED)) : 0.0f;   // (one lane: see below)
     if (t < B) {
         float e = 0.0f;
         for (int q = 0; q < a.Q; ++q) {
@@ -277,12 +292,23 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
                           0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
     const float s32[8] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
                           0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f};
-    const bool may_skip = a.run_lo != nullptr && a.thresh > 0.0f && a.thresh < 1.0f;
 #pragma unroll
     for (int g = 0; g < B; ++g) {
         const int64_t m0 = (b0 + g) * (int64_t)a.H;
         if (m0 < a.plen) {                             // (uniform)
-            lds_barrier();                             // everyone is done with both buffers
+            lds_barrier();                             // everyone is done with both buffers (and berr / l1p are in place)
+            {   // a block that cannot hold the maximum or a candidate gets no inverse transform at all
+                const float l1 = ((l1p[g * 4] + l1p[g * 4 + 1]) + (l1p[g * 4 + 2] + l1p[g * 4 + 3])) * (1.0001f / 8192.0f) + 5e-20f;
+                const float be0 = berr[g], run0 = berr[B];
+                if (may_skip && run0 > 0.0f && (l1 + be0) < a.thresh * run0 * (1.0f - 1e-6f) * 0.9999f) {   // (uniform)
+                    if (t == 0) {
+                        a.blk_max[b0 + g] = -INFINITY;
+                        a.blk_err[b0 + g] = be0;
+                        if (a.bad && !(be0 < INFINITY)) atomicOr(a.bad, 1ull);
+                    }
+                    continue;
+                }
+            }
             refresh();
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -319,8 +345,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
             if ((t & 63) == 0) red[g * 4 + wave] = mx;
-            // (one lane reads the shared bound -- 256 lanes hammering one address would serialise the whole grid)
-            if (t == 0) berr[B] = may_skip ? __int_as_float(__atomic_load_n(a.run_lo, __ATOMIC_RELAXED)) : 0.0f;
+            // (the shared bound was read by one lane above -- 256 lanes hammering one address would serialise the whole grid)
             lds_barrier();
             const float bmax = fmaxf(fmaxf(red[g * 4], red[g * 4 + 1]), fmaxf(red[g * 4 + 2], red[g * 4 + 3]));
             const float be = berr[g];
