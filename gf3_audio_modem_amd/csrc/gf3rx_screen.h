@@ -435,14 +435,6 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
         //  memory.  One lane reads it -- 256 lanes hammering one address would serialise the whole grid)
         float run_pre = 0.0f;
         if (may_skip && t == 0) run_pre = __int_as_float(__atomic_load_n(a.run_lo, __ATOMIC_RELAXED));
-        // Touch the samples the NEXT window adds (one element per 64 bytes or less, spread over the workgroup): they are
-        // in L2 when the next step asks for them, instead of a trip to HBM away with the first butterflies waiting.
-        // (A prefetch by ordinary load: the value is only handed to an empty asm at the end of the step.)
-        typename RawT<DT>::E touch = 0;
-        {
-            const int64_t ti = seg + 2 * NC + (int64_t)t * (a.H >> 8);
-            if (ti >= 0 && ti < a.n_in) touch = ((const typename RawT<DT>::E*)a.in)[ti];
-        }
         float e2 = scr_window_fft<DT>(a, seg, v, bufA, bufB, tw2, tw3, t);
         // Energy of the DROPPED part of this window's spectrum (what the truncation term of the bound multiplies: next
         // to a chirp the window is nearly all in-band and this is 1e-3 of its energy).  One-sided bins 1536 .. 4096:
@@ -595,7 +587,6 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
             for (int r = 0; r < KS; ++r) acc[i][r] = acc[i + 1][r];
 #pragma unroll
         for (int r = 0; r < KS; ++r) acc[RQ - 1][r] = cfmk(0.0f, 0.0f);
-        { float sink = (float)touch; asm volatile("" :: "v"(sink)); }
     }
 }
 
