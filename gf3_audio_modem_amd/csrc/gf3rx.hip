@@ -2131,8 +2131,7 @@ static hipError_t launch_screen(const gf3_ctx* c, ScreenArgs a, bool general, hi
         a.Hb = sp.d_Hb; a.ecoef = sp.d_ecoef; a.R = (int)R;
         const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (64 + 64 + 8 + 2 + 2 * GF3_SCR_RQ + 2) * sizeof(float);
         const int64_t grid = (((a.nblk + R - 1) / R + 7) / 8) * 8;                        // padded to the 8 XCDs (xcd_order)
-        if (a.Q <= 6) { DISPATCH_DT(a.dt, e = launch((scr_ring_kernel<DTC, 6>), grid, GF3_SCR_T, lds, st, a)); }
-        else { DISPATCH_DT(a.dt, e = launch((scr_ring_kernel<DTC, GF3_SCR_RQ>), grid, GF3_SCR_T, lds, st, a)); }
+        DISPATCH_DT(a.dt, e = launch((scr_ring_kernel<DTC>), grid, GF3_SCR_T, lds, st, a));
     } else {
         const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (128 + 11 * GF3_SCR_B + 4) * sizeof(float);
         const int64_t grid = (((a.nblk + GF3_SCR_B - 1) / GF3_SCR_B + 7) / 8) * 8;

@@ -392,12 +392,10 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
 // Used when Q <= RQ and the dropped share is small (build_screen_plan); otherwise scr_ols_kernel.
 #define GF3_SCR_KS 6                 /* slots t + 256 r, r < KS, of the half spectrum are kept (even: read in pairs) */
 #define GF3_SCR_RQ 8                 /* ring depth = largest Q */
-// RQ: ring depth of the instantiation, >= the plan's Q (6 serves every geometry of the reference up to CP = 704; the
-// deeper ring costs 24 registers and 24 moves per window)
-template <int DT, int RQ>
+template <int DT>
 __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
     extern __shared__ double2 smem[];
-    constexpr int NC = GF3_SCR_NC, T = GF3_SCR_T, KS = GF3_SCR_KS;
+    constexpr int NC = GF3_SCR_NC, T = GF3_SCR_T, KS = GF3_SCR_KS, RQ = GF3_SCR_RQ;
     cf* bufA = (cf*)smem;
     cf* bufB = bufA + NC;
     float* nrm = (float*)(bufB + NC);                 // [16][4] energy of window j in row j & 15, per wave
