@@ -11,6 +11,8 @@
 // is.  The lags above it (in cells of 14, with the two neighbours the extremum test needs) are re-evaluated ONCE as fp64
 // dot products with the fp64 replica; M is the largest of those values and the reference's rule is applied literally to
 // the same values.
+// Most blocks never get as far as P32: before the inverse transform the l1 norm of a block's accumulated spectrum bounds
+// every one of its lags, and a block that stays under thresh x (the grid's running lower bound of M) is dropped there.
 // No decision is ever taken on an fp32 value: fp32 only proves, with a margin, which lags need NOT be looked at.
 // If the screen is not selective (constant streams, pathological thresholds: more cells than the work list holds)
 // the caller falls back to the all-fp64 path (spec_kernel + ols_kernel), which is also what serves `d_corr`.
