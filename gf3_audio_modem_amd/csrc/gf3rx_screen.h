@@ -447,6 +447,23 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
         for (int m = 6; m < 10; ++m) { const cf z = v[scr_perm(m)]; eo = fmaf(z.x, z.x, fmaf(z.y, z.y, eo)); }
         { const cf z = v[scr_perm(10)]; const float g = t == 0 ? 1.0f : 0.0f; eo = fmaf(g * z.x, z.x, fmaf(g * z.y, z.y, eo)); }
         lds_barrier();
+        // The partitions' spectra for this window's multiply-adds are asked for in two batches of four, into registers
+        // the transform has just vacated: the first arrives under the split below, the second under the first batch's
+        // multiply-adds.  Fetched one partition at a time next to its own multiply-adds they cost six L2 round trips in
+        // a row: a third of the step (s_memtime stamps: 6.3 of 18.2 k cycles).
+        auto fetch_h = [&](float4 (&hb)[RQ / 2][KS / 2], int i0) {
+#pragma unroll
+            for (int ii = 0; ii < RQ / 2; ++ii) {
+                int h = a.Q - 1 - (i0 + ii);           // ring slot i holds block j - h
+                asm volatile("" : "+s"(h));            // (kept scalar and out of the loop-invariant set: hoisted, the partitions'
+                                                       //  per-lane 64-bit addresses are spilled around the transforms)
+                const float4* Hp = a.Hb + (int64_t)(h < 0 ? 0 : h) * (KS / 2) * T;    // (slots from Q on: fetched, never used)
+#pragma unroll
+                for (int p = 0; p < KS / 2; ++p) hb[ii][p] = Hp[(unsigned)(p * T + t)];
+            }
+        };
+        float4 hb0[RQ / 2][KS / 2], hb1[RQ / 2][KS / 2];
+        fetch_h(hb0, 0);
         // packed-real split, kept bins only: X[r] = 2 X[t + 256 r]  (k = 0 pairs with itself: its slot is 2 X[0], real)
         cf X[KS];
 #pragma unroll
@@ -460,25 +477,24 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
             const cf Pn = cfsub(Ee, Ow);               // ... and the partners 4096 - k of the kept bins (k = 0: the Nyquist bin), doubled like X
             eo = fmaf(0.25f * Pn.x, Pn.x, fmaf(0.25f * Pn.y, Pn.y, eo));
         }
+        asm volatile("" ::: "memory");                 // (the second batch is not to be hoisted over the split)
+        fetch_h(hb1, RQ / 2);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) { e2 += __shfl_xor(e2, d, 64); eo += __shfl_xor(eo, d, 64); }    // (two chains side by side)
         if (lane == 0) { nrm[(int)(j & 15) * 4 + wave] = e2; nro[(int)(j & 15) * 4 + wave] = eo; }
+        auto mac = [&](const float4 (&hb)[RQ / 2][KS / 2], int i0) {
 #pragma unroll
-        for (int i = 0; i < RQ; ++i) {
-            int h = a.Q - 1 - i;                       // ring slot i holds block j - h
-            asm volatile("" : "+s"(h));                // (kept scalar and out of the loop-invariant set: hoisted, the eight partitions'
-                                                       //  per-lane 64-bit addresses are spilled around the transforms)
-            if (h >= 0) {                              // (uniform)
-                const float4* Hp = a.Hb + (int64_t)h * (KS / 2) * T;
+            for (int ii = 0; ii < RQ / 2; ++ii)
+                if (i0 + ii < a.Q) {                   // (uniform)
 #pragma unroll
-                for (int p = 0; p < KS / 2; ++p) {
-                    const float4 hh = Hp[(unsigned)(p * T + t)];
-                    acc[i][2 * p] = cf_fma_conj(X[2 * p], cfmk(hh.x, hh.y), acc[i][2 * p]);
-                    acc[i][2 * p + 1] = cf_fma_conj(X[2 * p + 1], cfmk(hh.z, hh.w), acc[i][2 * p + 1]);
+                    for (int p = 0; p < KS / 2; ++p) {
+                        acc[i0 + ii][2 * p] = cf_fma_conj(X[2 * p], cfmk(hb[ii][p].x, hb[ii][p].y), acc[i0 + ii][2 * p]);
+                        acc[i0 + ii][2 * p + 1] = cf_fma_conj(X[2 * p + 1], cfmk(hb[ii][p].z, hb[ii][p].w), acc[i0 + ii][2 * p + 1]);
+                    }
                 }
-                asm volatile("" ::: "memory");        // one partition's loads in flight at a time
-            }
-        }
+        };
+        mac(hb0, 0);
+        mac(hb1, RQ / 2);
         const int64_t b = j - (a.Q - 1);               // the block this window completes
         if (b >= b0) {                                 // (uniform; the first Q - 1 windows only fill the ring)
             // ---- Can the block matter at all?  |y[i]| <= (1/N) sum_k |Y_k| over the two-sided spectrum: the l1 norm of the
