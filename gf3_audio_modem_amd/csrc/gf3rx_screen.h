@@ -50,6 +50,21 @@ GF3_DEV cf cf_fma_conj(cf a, cf h, cf c) {            // c + a conj(h)
     return cfmk(fmaf(a.x, h.x, fmaf(a.y, h.y, c.x)), fmaf(a.y, h.x, fmaf(-a.x, h.y, c.y)));
 }
 
+// Wave-wide sum / maximum of an fp32 value, the same in every lane: four DPP steps inside each row of 16 lanes
+// (quad swaps, then the two row mirrors) and the four row results through scalar registers.  The butterfly of
+// __shfl_xor it replaces is six ds_bpermute round trips through the LDS pipe, each waited for.
+template <bool MAX>
+GF3_DEV float scr_wave_reduce(float x) {
+    auto step = [](float v, float o) { return MAX ? fmaxf(v, o) : v + o; };
+    x = step(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true)));    // quad_perm [1,0,3,2]
+    x = step(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true)));    // quad_perm [2,3,0,1]
+    x = step(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, true)));   // row_half_mirror
+    x = step(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x140, 0xf, 0xf, true)));   // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return step(step(r0, r1), step(r2, r3));
+}
+
 // 4-point DFT in place: (a, b, c, d) = x0..x3  ->  X0..X3
 GF3_DEV void scr_dft4(cf& a, cf& b, cf& c, cf& d) {
     const cf s0 = cfadd(a, c), s1 = cfsub(a, c), s2 = cfadd(b, d), s3 = cf_negi(cfsub(b, d));
@@ -344,8 +359,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
                 if (i + 1 < W) mx = fmaxf(mx, fmaxf(y0, y1));
                 else if (i < W) mx = fmaxf(mx, y0);
             }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            mx = scr_wave_reduce<true>(mx);
             if ((t & 63) == 0) red[g * 4 + wave] = mx;
             // (the shared bound was read by one lane above -- 256 lanes hammering one address would serialise the whole grid)
             lds_barrier();
@@ -479,8 +493,8 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
         }
         asm volatile("" ::: "memory");                 // (the second batch is not to be hoisted over the split)
         fetch_h(hb1, RQ / 2);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { e2 += __shfl_xor(e2, d, 64); eo += __shfl_xor(eo, d, 64); }    // (two chains side by side)
+        e2 = scr_wave_reduce<false>(e2);
+        eo = scr_wave_reduce<false>(eo);
         if (lane == 0) { nrm[(int)(j & 15) * 4 + wave] = e2; nro[(int)(j & 15) * 4 + wave] = eo; }
         auto mac = [&](const float4 (&hb)[RQ / 2][KS / 2], int i0) {
 #pragma unroll
@@ -506,8 +520,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
                 float s1 = 0.0f;
 #pragma unroll
                 for (int r = 0; r < KS; ++r) s1 += sqrtf(fmaf(acc[0][r].x, acc[0][r].x, acc[0][r].y * acc[0][r].y));
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) s1 += __shfl_xor(s1, d, 64);
+                s1 = scr_wave_reduce<false>(s1);
                 if (lane == 0) red[4 + wave_s] = s1;
             }
             if (wave == 0) {                           // error bound of block b: windows b .. b + Q - 1, one per lane
@@ -570,8 +583,7 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
                 if (i + 1 < W) mx = fmaxf(mx, fmaxf(y0, y1));
                 else if (i < W) mx = fmaxf(mx, y0);
             }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+            mx = scr_wave_reduce<true>(mx);
             if (lane == 0) red[wave_s] = mx;
             lds_barrier();
             const float bmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
