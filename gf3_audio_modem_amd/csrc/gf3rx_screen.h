@@ -523,7 +523,14 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
                 s1 = scr_wave_reduce<false>(s1);
                 if (lane == 0) red[4 + wave_s] = s1;
             }
-            if (wave == 0) {                           // error bound of block b: windows b .. b + Q - 1, one per lane
+            if (t == 0) bc[1] = run_pre;
+            lds_barrier();                             // (also: every thread is done with the split's reads of bufA)
+            // Error bound of block b from the energies of windows b .. b + Q - 1.  The rows of THIS step's window were
+            // written by all four waves just above, so they are read after the barrier only -- and by every wave for
+            // itself (lane & 7 takes window b + (lane & 7); three DPP steps add the eight terms), which needs no second
+            // barrier to hand the result round.
+            float be;
+            {
                 const int ql = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 7;   // (= lane & 7, from the exec mask)
                 const float* n4 = nrm + (((int)(b & 15) + ql) & 15) * 4;
                 const float* o4 = n4 + 64;
@@ -531,13 +538,13 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
                 const float nx = sqrtf((n4[0] + n4[1]) + (n4[2] + n4[3]) + GF3_SCR_UFLOW) * 1.0001f;
                 const float no = sqrtf(((o4[0] + o4[1]) + (o4[2] + o4[3])) * (1.0f / 4096.0f) + GF3_SCR_UFLOW) * 1.0001f;
                 // (lanes from Q on look at rows that may never have been written: their term is dropped, not multiplied by 0)
-                float e = lane < a.Q ? fmaf(bc[2 + ql], nx, bc[10 + ql] * no) : 0.0f;
-#pragma unroll
-                for (int d = 8; d >= 1; d >>= 1) e += __shfl_xor(e, d, 64);
-                if (lane == 0) { bc[0] = e * 1.0001f + 1e-37f; bc[1] = run_pre; }
+                float e = ql < a.Q ? fmaf(bc[2 + ql], nx, bc[10 + ql] * no) : 0.0f;
+                e += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e), 0xB1, 0xf, 0xf, true));     // quad_perm [1,0,3,2]
+                e += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e), 0x4E, 0xf, 0xf, true));     // quad_perm [2,3,0,1]
+                e += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(e), 0x141, 0xf, 0xf, true));    // row_half_mirror
+                be = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(e))) * 1.0001f + 1e-37f;
             }
-            lds_barrier();                             // (also: every thread is done with the split's reads of bufA)
-            const float be = bc[0], run = bc[1];
+            const float run = bc[1];
             // acc holds 2 Y_k (the split's doubling), k >= 0 only: (1/8192) (|Y_0| + 2 sum_{k>0} |Y_k|) <= (1/8192) sum |acc_k|
             const float l1 = ((red[4] + red[5]) + (red[6] + red[7])) * (1.0001f / 8192.0f) + 5e-20f;   // (+: moduli whose squares underflowed, 1536 x 1.1e-19 at most)
             // (same rule as for the stores below: under thresh x an established lower bound of the maximum a block can hold
