@@ -790,6 +790,29 @@ def test_stream_screen_error_bound_holds(case, kernel):
         assert berr.max() > 4 * berr3.max()
 
 
+@pytest.mark.parametrize("kernel", ["band_limited", "general"])
+def test_stream_screen_is_reproducible(kernel):
+    """The screening pass, run six times over a 20 M-sample stream: the same block maxima and bounds bit for bit.  (A
+    bound read from LDS before every wave had written its share of it came out different once in a few runs.)"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("config3_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "config3.py"))
+    c3 = importlib.util.module_from_spec(spec); spec.loader.exec_module(c3)
+    eng, cfg, channel = c3.make_engine()
+    r, _ = c3.make_stream(eng, channel, 256)
+    eng.sync_stream_mode(3 if kernel == "general" else 2)
+    ref = None
+    for _ in range(6):
+        p32, bmax, berr, hop = eng.debug_stream_screen(r)
+        got = (p32.cpu().numpy(), bmax.cpu().numpy(), berr.cpu().numpy())
+        assert np.isfinite(got[2]).all()
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref, got):
+                assert np.array_equal(a, b)
+    eng.close()
+
+
 @pytest.mark.parametrize("name", LOOPBACKS)
 def test_stream_sync_screened_equals_fp64_path(name):
     """Both evaluations of chirp_method -- fp32 screen + fp64 decisions (default) and all-fp64 overlap-save -- return
