@@ -2127,7 +2127,7 @@ static hipError_t launch_screen(const gf3_ctx* c, ScreenArgs a, bool general, hi
         const int64_t slots = 2 * (int64_t)c->n_cu;                                       // workgroups resident at once
         const int64_t rounds = (a.nblk + slots * 170 - 1) / (slots * 170);
         int64_t R = sp.R_forced > 0 ? sp.R_forced : (a.nblk + slots * rounds - 1) / (slots * rounds);
-        if (R < 4) R = 4;
+        if (R < 1) R = 1;                                                                 // (short streams: one block per workgroup, Q windows each, all at once)
         a.Hb = sp.d_Hb; a.ecoef = sp.d_ecoef; a.R = (int)R;
         const size_t lds = (size_t)2 * GF3_SCR_NC * sizeof(cf) + (64 + 64 + 8 + 2 + 2 * GF3_SCR_RQ + 2) * sizeof(float);
         const int64_t grid = (((a.nblk + R - 1) / R + 7) / 8) * 8;                        // padded to the 8 XCDs (xcd_order)
