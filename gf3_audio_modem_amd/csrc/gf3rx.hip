@@ -2186,9 +2186,7 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
         const int64_t slots = 2 * (int64_t)c->n_cu;                         // (the LDS staging allows two workgroups per CU)
         const int64_t wgs = (w.s_cap + 3) / 4;                               // (a wave per cell at a time)
         const unsigned grid = (unsigned)(wgs < slots ? wgs : slots);
-        static const bool use_mfma = getenv("GF3_REFINE_MFMA") != nullptr;
-        if (use_mfma) { DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine_mfma_kernel<DTC>), dim3((unsigned)(4 * slots < wgs ? 4 * slots : wgs)), dim3(SCR_REF_THREADS), 0, st, a)); }
-        else { DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine_kernel<DTC>), dim3(grid), dim3(SCR_REF_THREADS), 0, st, a)); }
+        DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine_kernel<DTC>), dim3(grid), dim3(SCR_REF_THREADS), 0, st, a));
         HIPCHK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(scr_decide_kernel, dim3((unsigned)((w.s_cap + 255) / 256)), dim3(256), 0, st, (const int64_t*)cell, (const double*)cval, misc,
