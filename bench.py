@@ -291,7 +291,10 @@ def stream_sync_roofline(dev, frames=4096):
                                     "achieved": by / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS,
                                     "algorithmic_bytes_per_call": by, "call_ms": t * 1e3, "demod_ms": res["demod_s"] * 1e3,
                                     "samples_per_s_sync_plus_demod": res["samples_per_s"], "ber_vs_payload": res["ber"],
-                                    "sync_offsets_exact": res["sync_offsets_as_expected_plus1"]}}
+                                    "sync_offsets_exact": res["sync_offsets_as_expected_plus1"],
+                                    "sync_path": eng.sync_stream_info(),
+                                    "limiter": "fp32 VALU issue of the screening transforms (two waves per SIMD at 256 registers; clock not "
+                                               "throttled); measured HBM traffic 1.5 x the algorithmic bytes (DESIGN.md section 3.1, profiles/)"}}
     eng.close()
     return out
 
