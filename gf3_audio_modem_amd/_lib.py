@@ -43,6 +43,8 @@ _SIGS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "gf3_sync_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, c_i64_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gf3_sync_stream_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, c_i64_p,
+                                     C.c_void_p, C.c_void_p, C.c_int32, c_i64_p, C.c_void_p]),
     "gf3_sync_stream_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "gf3_sync_stream_info": (C.c_int, [C.c_void_p, c_i64_p]),
     "gf3_debug_stream_screen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),

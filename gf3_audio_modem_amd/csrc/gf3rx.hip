@@ -6,10 +6,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <vector>
 
 #include "gf3rx.h"
 #include "gf3rx_device.h"
+#include "gf3rx_fft16.h"
 #include "gf3rx_screen.h"
 
 // ============================================================================
@@ -595,6 +597,15 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 #ifndef GF3_CORR_PP
 #define GF3_CORR_PP true
 #endif
+#ifndef GF3_CORR16_PROBE
+#define GF3_CORR16_PROBE 0
+#endif
+#ifndef GF3_CORR16_LATE
+#define GF3_CORR16_LATE 0     /* 1: the next segment's samples are fetched into registers under the last multiply-accumulate */
+#endif
+#ifndef GF3_CORR16
+#define GF3_CORR16 1          /* plans of 2048-point transforms run corr16_kernel (one wave, 16 points per thread) */
+#endif
 template <int NC, int DT>
 __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_kernel(CorrArgs a) {
     extern __shared__ double2 smem[];
@@ -726,6 +737,163 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         }
     }
     first = block_min_i(first, (int*)(scratch + 16));
+    if (tid == 0) {
+        const bool found = first != 0x7fffffff;
+        a.starts[b] = found ? (s0 + first + a.Lc) : -1;
+        if (a.peak) a.peak[b] = found ? y[first] : 0.0;
+    }
+}
+
+// ============================================================================
+// The same correlator on the one-wave, 16-points-per-thread transform (gf3rx_fft16.h) for plans of 2048-point
+// transforms (NC = 1024: the frames plan of every N = 4096 geometry): one search window per 64-thread workgroup,
+// two LDS exchanges per transform instead of three, and no s_barrier at all -- the eight waves of a CU work on
+// eight different windows and drift apart.  Same arguments, same results to rounding (the transform's passes are
+// 16 . 16 . 4 instead of 8 . 8 . 4 . 4).
+// ============================================================================
+template <int DT>
+__global__ __launch_bounds__(64, 2) void corr16_kernel(CorrArgs a) {
+    extern __shared__ double2 smem[];
+    constexpr int NC = 1024, T = 64;
+    cplx* lds = smem;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    const int64_t s0 = b * a.stride + a.win_lo;
+    const int W = a.W;
+    F16Tw ft;
+    ft.init(tid, a.t.tw, a.t.twn);
+    cplx acc[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = cmk(0.0, 0.0);
+    double accDC = 0.0, accNy = 0.0;
+    // samples of a segment that reach valid lags, rounded up to whole strided loads (128 samples): a load is then
+    // either wholly wanted or wholly zero, with no per-lane predicate (the extra samples only reach lags >= W)
+    const int nfull = (a.Lp + a.Wmax - 1 + 2 * T - 1) / (2 * T);
+    typedef typename RawT<DT>::E E;
+    RawPair<DT> nxt[16];
+    auto fetch = [&](int q) {
+        const int64_t seg = s0 + (int64_t)q * a.Lp;
+        const E* base = (const E*)a.in + seg;                            // wave-uniform
+        const unsigned t2 = 2u * (unsigned)tid;
+        if (seg >= 0 && seg + 2 * NC <= a.n_in) {                        // (uniform) the segment lies inside the buffer
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { if (r < nfull) nxt[r].load_u(base, t2 + (unsigned)(2 * T * r)); else nxt[r].zero(); }
+        } else {                                                         // buffer edges: clamped addresses, selects
+            const int64_t last = a.n_in - 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t i0 = seg + 2 * T * r + 2 * tid, i1 = i0 + 1;
+                const int64_t c0 = i0 < 0 ? 0 : (i0 > last ? last : i0), c1 = i1 < 0 ? 0 : (i1 > last ? last : i1);
+                const E e0 = ((const E*)a.in)[c0], e1 = ((const E*)a.in)[c1];
+                nxt[r].v.a = (r < nfull && c0 == i0) ? e0 : (E)0;
+                nxt[r].v.b = (r < nfull && c1 == i1) ? e1 : (E)0;
+            }
+        }
+    };
+    // One-register prefetch of a segment into L2: lane l touches the 128-byte line l of the segment's 64 (f32) or fewer.
+    // The 32 registers of the real loads are then only needed from the last multiply-accumulate of a transform to the
+    // start of the next one, when nothing else of the transform is live, and those loads hit L2.
+    auto touch = [&](int q) {
+        const int64_t seg = s0 + (int64_t)q * a.Lp;
+        int64_t i = seg + (int64_t)tid * (128 / (int)sizeof(E));
+        i = i < 0 ? 0 : (i >= a.n_in ? a.n_in - 1 : i);
+        const float x = (float)((const E*)a.in)[i];
+        asm volatile("" :: "v"(x));                                      // (keeps the load; its value is not used)
+    };
+#if GF3_CORR16_LATE || GF3_CORR16_PROBE
+    fetch(0);
+    if (a.Q > 1) touch(1);
+#else
+    touch(0);
+    if (a.Q > 1) touch(1);
+#endif
+    cplx v[16], z0;
+    for (int q = 0; q < a.Q; ++q) {
+        const cplx* Hq = a.Hq + (int64_t)q * (NC + 1);
+#if !GF3_CORR16_LATE && !GF3_CORR16_PROBE
+        fetch(q);                                                        // (L2 hits: touched a transform ago)
+#endif
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = nxt[r].get();
+#if GF3_CORR16_PROBE     /* timing probe, WRONG results: four accumulators instead of sixteen, so that the early register prefetch fits */
+        if (q + 1 < a.Q) fetch(q + 1);
+#define ACC16(i) acc[(i) & 3]
+#else
+#define ACC16(i) acc[i]
+#endif
+        if (q + 2 < a.Q) touch(q + 2);
+        ft.refresh();
+        f16_passes12(v, lds, ft, tid);
+        // the spectrum in two halves of eight slots, each multiplied into the accumulators at once (four fma per slot)
+        {
+            cplx o[8], hq[8];
+            rfft16_half<true, 0>(o, lds, ft, tid, z0);                   // slots hold 2 X: undone by `inv` below
+#pragma unroll
+            for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec16::bin(tid, s)];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) ACC16(s) = cfma(o[s], cconj(hq[s]), ACC16(s));
+        }
+        {
+            cplx o[8], hq[8];
+            rfft16_half<true, 1>(o, lds, ft, tid, z0);
+#if GF3_CORR16_LATE
+            wave_lds_fence();
+            if (q + 1 < a.Q) fetch(q + 1);
+#endif
+#pragma unroll
+            for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec16::bin(tid, 8 + s)];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) ACC16(8 + s) = cfma(o[s], cconj(hq[s]), ACC16(8 + s));
+        }
+        if (tid == 0) {
+            accDC += (z0.x + z0.y) * Hq[0].x;
+            accNy += (z0.x - z0.y) * Hq[NC].x;
+        }
+    }
+    // ---- inverse real FFT of the accumulated Hermitian spectrum Y (construction as in corr_kernel)
+    wave_lds_fence();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int k = Spec16::bin(tid, 2 * p);
+        const cplx wk = p < 4 ? Spec<1024>::pair_tw(tid, p, ft.wb) : Spec<1024>::pair_tw(1, p - 4, ft.wb2());
+        const cplx A = acc[2 * p];
+        const cplx B = cconj(acc[2 * p + 1]);
+        const cplx E2 = cscale(cadd(A, B), 0.5);
+        const cplx Op = cmul_conj(cscale(csub(A, B), 0.5), wk);          // * exp(+2 pi i k/N)
+        const cplx Zk = cadd(E2, mul_posi(Op));
+        const cplx Zm = cadd(cconj(E2), mul_posi(cconj(Op)));
+        lds[k] = cconj(Zk);
+        if (Spec16::live(tid, 2 * p + 1)) lds[NC - k] = cconj(Zm);
+    }
+    if (tid == 0) {
+        const double E2 = accDC + accNy, Op = accDC - accNy;
+        lds[0] = cmk(E2, -Op);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = lds[tid + r * T];
+    ft.refresh();
+    f16_fft(v, lds, ft, tid);
+    const double inv = 0.5 / (double)NC;
+    for (int i = tid; i < NC; i += T) { const cplx z = lds[i]; lds[i] = cmk(z.x * inv, -z.y * inv); }
+    wave_lds_fence();
+    const double* y = (const double*)lds;
+
+    // ---- peak rule on the window (OFDM.py:359-361), as corr_kernel; the workgroup is one wave
+    double mx = -INFINITY;
+    for (int j = tid; j < W; j += T) mx = fmax(mx, y[j]);
+    mx = wave_max(mx);
+    int first = 0x7fffffff;
+    const bool filt = mx > 0.0 && a.thresh > 0.0 && mx < INFINITY && a.thresh < INFINITY;
+    const double lim = filt ? a.thresh * mx * (1.0 - 1e-6) : -INFINITY;
+    for (int j = 1 + tid; j < W - 1; j += T) {
+        const double y0 = y[j];
+        if (!(y0 < lim)) {
+            const double pm1 = y[j - 1] / mx, p0 = y0 / mx, pp1 = y[j + 1] / mx;
+            if (((p0 - pm1) * (pp1 - p0) <= 0.0) && (p0 > a.thresh)) first = min(first, j);
+        }
+    }
+    first = wave_min_i(first);
     if (tid == 0) {
         const bool found = first != 0x7fffffff;
         a.starts[b] = found ? (s0 + first + a.Lc) : -1;
@@ -1358,16 +1526,20 @@ struct gf3_ctx {
     struct { bool ok = false; int Q = 0, H = 0; cf *d_tw = nullptr, *d_twn = nullptr; float4* d_Hs = nullptr;
              float *d_H0N = nullptr, *d_Hinf = nullptr;
              bool ring = false; float4* d_Hb = nullptr; float* d_ecoef = nullptr; int R_forced = 0; } scr;   // band-limited kernel (scr_ring_kernel)
-    int stream_mode = 0;                // 0: by stream length (screen from GF3_SCR_MIN_SAMPLES on); 1: fp64 only; 2: screen whenever a plan exists; 3: as 2 with the general kernel
-    int64_t last_info[4] = {0, 0, 0, 0};   // last gf3_sync_stream: path taken (0 screened, 1 fp64 after fallback, 2 fp64), cells re-evaluated, cells holding a candidate, candidates
+    // The ONLY field a call may write after gf3_ctx_create: the default evaluation mode of the legacy entry point
+    // gf3_sync_stream (gf3_sync_stream_mode sets it; gf3_sync_stream_ex takes the mode per call and never reads it).
+    // 0: by stream length (screen from GF3_SCR_MIN_SAMPLES on); 1: fp64 only; 2: screen whenever a plan exists; 3: as 2 with the general kernel
+    std::atomic<int> default_stream_mode{0};
     std::vector<double> chirp;
     std::vector<cplx> known_pts;
-    mutable char err[512];
 };
 
-// message of a failure that has no context to carry it (gf3_ctx_create, null ctx): one buffer per calling thread,
-// so concurrent callers on different host threads do not overwrite each other's text
+// Message of the calling thread's last failure.  One buffer per host thread, none in the context: concurrent calls
+// on one context (different streams, different threads) cannot overwrite each other's text, and a failing call
+// writes nothing into the context it was given.
 static thread_local char g_err[512] = "";
+// ... and the diagnostics of the calling thread's last gf3_sync_stream / gf3_sync_stream_ex (gf3_sync_stream_info)
+static thread_local int64_t g_last_info[4] = {0, 0, 0, 0};
 
 // Scratch device allocations of the set-up helpers: released on every return path.
 struct DevTmp {
@@ -1392,13 +1564,11 @@ struct DeviceGuard {
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
-static int fail(const gf3_ctx* c, int code, const char* fmt, ...) {
+static int fail(const gf3_ctx*, int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    char* dst = c ? c->err : g_err;
-    vsnprintf(dst, 512, fmt, ap);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
-    if (c) memcpy(g_err, c->err, 512);
     return code;
 }
 #define HIPCHK(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
@@ -1589,7 +1759,7 @@ static int build_screen_plan(gf3_ctx* c) {
 
 extern "C" const char* gf3_version(void) { return GF3RX_VERSION; }
 
-extern "C" const char* gf3_last_error(const gf3_ctx* ctx) { return ctx ? ctx->err : g_err; }
+extern "C" const char* gf3_last_error(const gf3_ctx*) { return g_err; }
 
 extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     if (!cfg || !out) return fail(nullptr, GF3_EINVAL, "null argument");
@@ -1605,7 +1775,6 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     if (cfg->in_dtype < 0 || cfg->in_dtype > 3) return fail(nullptr, GF3_EINVAL, "bad in_dtype");
     gf3_ctx* c = new gf3_ctx();
     c->cfg = *cfg;
-    c->err[0] = 0;
     if (hipGetDevice(&c->device) != hipSuccess) { delete c; return fail(nullptr, GF3_EHIP, "hipGetDevice failed: no usable GPU"); }
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || c->n_cu < 1) c->n_cu = 256;
     c->NC = N / 2; c->K = N / 2 - 1; c->S = N + cfg->CP;
@@ -1780,7 +1949,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     if (rc == GF3_OK) rc = build_plan(c, &c->stream_plan, NCs, ts, NCs);
     if (rc == GF3_OK) rc = build_known_time(c);
     if (rc == GF3_OK) rc = build_screen_plan(c);
-    if (rc != GF3_OK) { memcpy(g_err, c->err, 512); gf3_ctx_destroy(c); return rc; }
+    if (rc != GF3_OK) { gf3_ctx_destroy(c); return rc; }
     *out = c;
     return GF3_OK;
 }
@@ -2036,6 +2205,16 @@ static hipError_t run_corr(const gf3_ctx* c, const CorrPlan& pl, const CorrArgs&
     const int NCp = pl.NC;
     const size_t lds = (GF3_CORR_PP ? fft_lds_bytes(NCp) : (size_t)(NCp + NCp / 8) * sizeof(cplx)) + 32 * sizeof(double);
     hipError_t e = hipSuccess;
+#if GF3_CORR16
+    if (NCp == 1024 && a.dt != DT_F64) {              // one-wave transforms (f64 samples: no room for the prefetch)
+        const size_t lds16 = (size_t)1024 * sizeof(cplx);
+        if (a.dt == DT_F32) return launch((corr16_kernel<DT_F32>), grid, 64, lds16, st, a);
+#ifndef GF3_DEV_BUILD
+        if (a.dt == DT_I16) return launch((corr16_kernel<DT_I16>), grid, 64, lds16, st, a);
+        return launch((corr16_kernel<DT_U8>), grid, 64, lds16, st, a);
+#endif
+    }
+#endif
 #ifdef GF3_DEV_BUILD
     if (NCp == 1024) {
         if (a.dt == DT_F64) return launch((corr_kernel<1024, DT_F64>), grid, 128, lds, st, a);
@@ -2142,8 +2321,8 @@ static hipError_t launch_screen(const gf3_ctx* c, ScreenArgs a, bool general, hi
 
 // Screened path of gf3_sync_stream (gf3rx_screen.h).  Enqueues everything on `st`; the caller reads back
 // {peaks, suppression status} at np and the ScrMisc block.
-static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const StreamWs& w, char* base, int64_t* d_peaks,
-                                int64_t cap, hipStream_t st) {
+static int sync_stream_screened(const gf3_ctx* c, const void* d_r, int64_t n, const StreamWs& w, char* base, int64_t* d_peaks,
+                                int64_t cap, int mode, hipStream_t st) {
     const auto& sp = c->scr;
     float* P32 = (float*)(base + w.o_P);
     float* blk_max = (float*)(base + w.o_sblk);
@@ -2167,7 +2346,7 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
         ScreenArgs a{d_r, n, dt, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, w.s_nblk, w.plen,
                      P32, blk_max, blk_err, (int*)(base + w.o_smisc + sizeof(ScrMisc)), (float)c->cfg.thresh, nullptr, nullptr, 0,
                      (unsigned long long*)&misc->status};
-        HIPCHK(c, launch_screen(c, a, c->stream_mode == 3, st));
+        HIPCHK(c, launch_screen(c, a, mode == 3, st));
     }
     // 2. the cells whose lags the bounds cannot exclude, in ascending order (flag + count, scan, scatter)
     {
@@ -2208,12 +2387,12 @@ static int sync_stream_screened(gf3_ctx* c, const void* d_r, int64_t n, const St
 extern "C" int gf3_sync_stream_mode(gf3_ctx* c, int32_t mode) {
     if (!c || mode < 0 || mode > 3)
         return fail(c, GF3_EINVAL, "gf3_sync_stream_mode: mode must be 0 (by length), 1 (fp64 only), 2 (always screen) or 3 (always screen, general kernel)");
-    c->stream_mode = mode;
+    c->default_stream_mode.store(mode, std::memory_order_relaxed);
     return GF3_OK;
 }
 extern "C" int gf3_sync_stream_info(const gf3_ctx* c, int64_t* h_out4) {
     if (!c || !h_out4) return fail(c, GF3_EINVAL, "null argument");
-    memcpy(h_out4, c->last_info, sizeof(c->last_info));
+    memcpy(h_out4, g_last_info, sizeof(g_last_info));
     return GF3_OK;
 }
 // tests: the screening pass alone.  d_p32 [n + Lc - 1] float, d_blk [2 * nblk] float (block maxima, then block error
@@ -2227,15 +2406,15 @@ extern "C" int gf3_debug_stream_screen(gf3_ctx* c, const void* d_r, int64_t n, f
     *h_hop = sp.H;
     ScreenArgs a{d_r, n, c->cfg.in_dtype, sp.d_tw, sp.d_twn, sp.d_Hs, sp.d_H0N, sp.d_Hinf, sp.Q, sp.H, c->Lc, nblk, plen,
                  d_p32, d_blk, d_blk + nblk, nullptr, 0.0f, nullptr, nullptr, 0, nullptr};      // (no skipping: the tests look at every lag)
-    HIPCHK(c, launch_screen(c, a, c->stream_mode == 3, (hipStream_t)stream));
+    HIPCHK(c, launch_screen(c, a, c->default_stream_mode.load(std::memory_order_relaxed) == 3, (hipStream_t)stream));
     return GF3_OK;
 }
 
-extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* d_peaks, int64_t cap,
-                               int64_t* n_peaks, void* d_work, double* d_corr, void* stream) {
+extern "C" int gf3_sync_stream_ex(const gf3_ctx* c, const void* d_r, int64_t n, int64_t* d_peaks, int64_t cap,
+                                  int64_t* n_peaks, void* d_work, double* d_corr, int32_t mode, int64_t* h_info4, void* stream) {
     DeviceGuard dg(c);
-    if (!c || !d_r || !d_peaks || !n_peaks || !d_work || n < 3 || cap < 1)
-        return fail(c, GF3_EINVAL, "gf3_sync_stream: bad argument");
+    if (!c || !d_r || !d_peaks || !n_peaks || !d_work || n < 3 || cap < 1 || mode < 0 || mode > 3)
+        return fail(c, GF3_EINVAL, "gf3_sync_stream: bad argument (mode must be 0 by length, 1 fp64 only, 2 always screen, 3 always screen with the general kernel)");
     hipStream_t st = (hipStream_t)stream;
     const StreamWs w = stream_ws(c, n);
     char* base = (char*)d_work;
@@ -2248,22 +2427,27 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     int64_t* total = (int64_t*)(base + w.o_misc + 8);
     int64_t* np = (int64_t*)(base + w.o_misc + 16);        // [count, status]
     const CorrPlan& pl = c->stream_plan;
-    c->last_info[0] = 2; c->last_info[1] = c->last_info[2] = c->last_info[3] = 0;
-    if (!d_corr && c->scr.ok && w.s_nblk > 0 && (c->stream_mode >= 2 || (c->stream_mode == 0 && n >= GF3_SCR_MIN_SAMPLES))) {
-        int rc = sync_stream_screened(c, d_r, n, w, base, d_peaks, cap, st);
+    // diagnostics of this call: the caller's array when given, and always the calling thread's own copy
+    // (gf3_sync_stream_info); nothing of a call is kept in the context
+    int64_t info_local[4];
+    int64_t* info = h_info4 ? h_info4 : info_local;
+    struct Publish { int64_t* i; ~Publish() { memcpy(g_last_info, i, sizeof(g_last_info)); } } publish{info};
+    info[0] = 2; info[1] = info[2] = info[3] = 0;
+    if (!d_corr && c->scr.ok && w.s_nblk > 0 && (mode >= 2 || (mode == 0 && n >= GF3_SCR_MIN_SAMPLES))) {
+        int rc = sync_stream_screened(c, d_r, n, w, base, d_peaks, cap, mode, st);
         if (rc != GF3_OK) return rc;
         ScrMisc hm;
         HIPCHK(c, hipMemcpyAsync(&hm, base + w.o_smisc, sizeof(ScrMisc), hipMemcpyDeviceToHost, st));      // (the one read-back of the call)
         HIPCHK(c, hipStreamSynchronize(st));
         const int64_t h[2] = {hm.np[0], hm.np[1]}, ncand = hm.total;
-        c->last_info[1] = hm.ncell; c->last_info[2] = hm.nhit; c->last_info[3] = ncand;
+        info[1] = hm.ncell; info[2] = hm.nhit; info[3] = ncand;
         if (!(hm.status & 1)) {
-            c->last_info[0] = 0;
+            info[0] = 0;
             *n_peaks = h[0];
             if (h[1] == 2) return fail(c, GF3_ERANGE, "gf3_sync_stream: %lld peaks exceed capacity %lld", (long long)h[0], (long long)cap);
             return GF3_OK;
         }
-        c->last_info[0] = 1;                              // the screen was not selective: all-fp64 path below
+        info[0] = 1;                                      // the screen was not selective: all-fp64 path below
     }
     {
         OlsArgs a{};
@@ -2302,6 +2486,13 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
     *n_peaks = h[0];
     if (h[1] == 2) return fail(c, GF3_ERANGE, "gf3_sync_stream: %lld peaks exceed capacity %lld", (long long)h[0], (long long)cap);
     return GF3_OK;
+}
+
+// the legacy entry point: the context's default mode (gf3_sync_stream_mode), diagnostics through gf3_sync_stream_info
+extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* d_peaks, int64_t cap,
+                               int64_t* n_peaks, void* d_work, double* d_corr, void* stream) {
+    if (!c) return fail(c, GF3_EINVAL, "gf3_sync_stream: bad argument");
+    return gf3_sync_stream_ex(c, d_r, n, d_peaks, cap, n_peaks, d_work, d_corr, c->default_stream_mode.load(std::memory_order_relaxed), nullptr, stream);
 }
 
 static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, uint8_t* idx, float* llr, double nv, void* stream);

@@ -133,52 +133,70 @@ def spawn_ranks(cmd, n, port=None, env=None, relay=None, poll_s=0.2, grace_s=10.
     the GPU: the children are plain subprocess.Popen children (never os.exec*), each initialises its own device.
     Rank 0's stdout is relayed line by line through `relay` (default: print), the other ranks' stdout is dropped
     (they print nothing by contract), stderr is inherited.  If a rank exits non-zero the others are given
-    `grace_s` seconds and then terminated by their exact PIDs.  Returns (rc, rank-0 stdout lines): rc is 0 only if
-    every rank returned 0, else the first non-zero code by rank order."""
+    `grace_s` seconds and then terminated by their exact PIDs.  Whatever ends the wait -- normal completion, an
+    exception, KeyboardInterrupt, a SIGTERM turned into SystemExit by the caller's handler -- no child is left
+    behind: every one still running is terminated, then killed, by its exact PID.
+    Returns (rc, rank-0 stdout lines): rc is 0 only if every rank returned 0, else the exit code of the rank that
+    failed FIRST of its own accord (not the -15 of a straggler this function terminated afterwards).
+    port: rendezvous port; None picks a free one (the probe socket stays bound until the children exist, which
+    narrows, but cannot close, the window in which another job could take the port: pass a port to be sure)."""
     import socket
     import subprocess
     import sys
-    import time
-    if port is None:
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-    relay = relay or (lambda line: (sys.stdout.write(line + "\n"), sys.stdout.flush()))
-    procs = []
-    for r in range(n):
-        e = dict(os.environ if env is None else env)
-        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen(list(cmd), env=e, text=True,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    lines = []
     import threading
+    import time
+    probe = None
+    if port is None:
+        probe = socket.socket()
+        probe.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    relay = relay or (lambda line: (sys.stdout.write(line + "\n"), sys.stdout.flush()))
+    procs, lines = [], []
+    first_failure = None                                      # (rank, code) of the first rank that failed by itself
+    pump_thread = None
+    try:
+        for r in range(n):
+            e = dict(os.environ if env is None else env)
+            e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                     MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen(list(cmd), env=e, text=True,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        if probe is not None:
+            probe.close()                                     # (the ranks bind it seconds later, after their imports)
+            probe = None
 
-    def pump():
-        for line in procs[0].stdout:
-            line = line.rstrip("\n")
-            lines.append(line)
-            relay(line)
-    t = threading.Thread(target=pump, daemon=True)
-    t.start()
-    failed_at = None
-    while any(p.poll() is None for p in procs):
-        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
-            failed_at = time.monotonic()
-        if failed_at is not None and time.monotonic() - failed_at > grace_s:
-            for p in procs:                                   # exact PIDs of our own children only
-                if p.poll() is None:
-                    p.terminate()
-            for p in procs:
-                try:
-                    p.wait(timeout=5)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-            break
-        time.sleep(poll_s)
-    t.join(timeout=5)
-    rcs = [p.wait() for p in procs]
-    rc = next((c for c in rcs if c != 0), 0)
-    return rc, lines
-
+        def pump():
+            for line in procs[0].stdout:
+                line = line.rstrip("\n")
+                lines.append(line)
+                relay(line)
+        pump_thread = threading.Thread(target=pump, daemon=True)
+        pump_thread.start()
+        failed_at = None
+        while any(p.poll() is None for p in procs):
+            if first_failure is None:
+                for r, p in enumerate(procs):
+                    if p.poll() not in (None, 0):
+                        first_failure, failed_at = (r, p.returncode), time.monotonic()
+                        break
+            if failed_at is not None and time.monotonic() - failed_at > grace_s:
+                break                                         # the finally block ends the stragglers
+            time.sleep(poll_s)
+    finally:
+        if probe is not None:
+            probe.close()
+        for p in procs:                                       # exact PIDs of our own children only
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        if pump_thread is not None:
+            pump_thread.join(timeout=5)
+    if first_failure is None:                                 # (a failure between the last poll and the loop's exit)
+        first_failure = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+    return (first_failure[1] if first_failure else 0), lines

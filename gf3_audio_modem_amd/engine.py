@@ -8,6 +8,7 @@ library, constructing an Engine raises.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -145,6 +146,8 @@ class Engine:
             msg = self.lib.gf3_last_error(None).decode()
             raise (ValueError if rc == _lib.GF3_EINVAL else Gf3Error)(msg)
         self._h = h
+        self._sync_mode = 0
+        self._tls = threading.local()
         self.bytes_per_frame = int(self.lib.gf3_bytes_per_frame(h))
         self.max_window = int(self.lib.gf3_sync_max_window(h))
 
@@ -251,8 +254,13 @@ class Engine:
                                              _ptr(starts), _ptr(peak), self._stream()))
         return (starts, peak) if want_peak else starts
 
-    def sync_stream(self, x, cap=None, want_corr=False):
-        """chirp_method on one stream: indices i with zeros[i] True (int64 tensor)."""
+    def sync_stream(self, x, cap=None, want_corr=False, mode=None, want_info=False):
+        """chirp_method on one stream: indices i with zeros[i] True (int64 tensor).
+        mode: how the matched filter is evaluated for THIS call (gf3_sync_stream_ex; None = the engine's default set by
+        sync_stream_mode): 0 fp32 screening + fp64 decisions from 2^23 samples on, all-fp64 below; 1 always the all-fp64
+        overlap-save; 2 screened at any length; 3 as 2 with the general screening kernel.  want_info adds the call's
+        diagnostics dict (as sync_stream_info) to the result.  Nothing of a call is stored in the C context, so several
+        threads may run this on one engine, each on its own stream."""
         x = self._samples(x).reshape(-1)
         n = x.numel()
         Lc = self.cfg.chirp_length
@@ -262,24 +270,26 @@ class Engine:
         work = self._new((ws,), torch.uint8)
         corr = self._new((n + Lc - 1,), torch.float64) if want_corr else None
         cnt = C.c_int64(0)
-        self._check(self.lib.gf3_sync_stream(self._h, _ptr(x), n, _ptr(peaks), cap, C.byref(cnt), _ptr(work),
-                                             _ptr(corr), self._stream()))
+        info = (C.c_int64 * 4)()
+        self._check(self.lib.gf3_sync_stream_ex(self._h, _ptr(x), n, _ptr(peaks), cap, C.byref(cnt), _ptr(work),
+                                                _ptr(corr), int(self._sync_mode if mode is None else mode), info, self._stream()))
         peaks = peaks[: cnt.value]
-        return (peaks, corr) if want_corr else peaks
+        d = dict(path=int(info[0]), cells=int(info[1]), cells_hit=int(info[2]), candidates=int(info[3]))
+        self._tls.sync_info = d
+        out = (peaks,) + ((corr,) if want_corr else ()) + ((d,) if want_info else ())
+        return out[0] if len(out) == 1 else out
 
     def sync_stream_mode(self, mode):
-        """gf3_sync_stream_mode: 0 (default) fp32 screening + fp64 decisions from 2^23 samples on, all-fp64 below;
-        1 always the all-fp64 overlap-save path; 2 screened at any length; 3 as 2 with the general screening kernel
-        where the band-limited one would run.  (A screen that is not selective, and any call that asks for P, takes
-        the all-fp64 path regardless.)"""
-        self._check(self.lib.gf3_sync_stream_mode(self._h, int(mode)))
+        """Default `mode` of sync_stream for this Engine object (a Python-side default: the C context is not touched)."""
+        if int(mode) not in (0, 1, 2, 3):
+            raise ValueError("sync_stream_mode: mode must be 0 (by length), 1 (fp64 only), 2 (always screen) or 3 (always screen, general kernel)")
+        self._sync_mode = int(mode)
+        self._check(self.lib.gf3_sync_stream_mode(self._h, int(mode)))      # (keeps debug_stream_screen's kernel choice in step)
 
     def sync_stream_info(self):
-        """Of the last sync_stream call: dict(path=0 screened | 1 fp64 after a non-selective screen | 2 fp64,
-        cells = cells of 14 lags re-evaluated in fp64, cells_hit = those holding a candidate, candidates)."""
-        out = (C.c_int64 * 4)()
-        self._check(self.lib.gf3_sync_stream_info(self._h, out))
-        return dict(path=int(out[0]), cells=int(out[1]), cells_hit=int(out[2]), candidates=int(out[3]))
+        """Of the calling thread's last sync_stream call: dict(path=0 screened | 1 fp64 after a non-selective screen |
+        2 fp64, cells = cells of 14 lags re-evaluated in fp64, cells_hit = those holding a candidate, candidates)."""
+        return dict(getattr(self._tls, "sync_info", dict(path=2, cells=0, cells_hit=0, candidates=0)))
 
     def debug_stream_screen(self, x):
         """The fp32 screening pass alone (tests): (P32 [n+Lc-1] float32, block maxima, block error bounds, hop)."""

@@ -16,8 +16,13 @@
  *     look-up tables.  `stream` is a hipStream_t passed as void* (NULL = the
  *     default stream).  All work is enqueued asynchronously on that stream;
  *     only gf3_sync_stream synchronises (it returns a count to the host).
- *   - a context is immutable after creation: concurrent calls on different
- *     streams are safe.
+ *   - a context is immutable after creation: no call writes into it, so
+ *     concurrent calls on one context from different host threads / on
+ *     different streams are safe (every call brings its own workspace and
+ *     outputs; error text and diagnostics are kept per calling THREAD, not in
+ *     the context).  The one exception is the legacy convenience
+ *     gf3_sync_stream_mode, which stores a default mode for the legacy entry
+ *     point gf3_sync_stream; gf3_sync_stream_ex takes the mode per call.
  *   - complex128 arrays are interleaved (re, im) doubles, as NumPy stores them.
  */
 #ifndef GF3RX_H
@@ -81,6 +86,7 @@ const char *gf3_version(void);
  * chirp replica and its partition spectra, demap tables, on the current device */
 int gf3_ctx_create(const gf3_config *cfg, gf3_ctx **out);
 void gf3_ctx_destroy(gf3_ctx *ctx);
+/* message of the CALLING THREAD's last failed call (the argument is ignored: nothing is stored in a context) */
 const char *gf3_last_error(const gf3_ctx *ctx);
 
 /* diagnostics: in a library built with -DGF3_STAMPS, gf3_demod_frames writes eight s_memtime
@@ -164,7 +170,7 @@ int gf3_sync_stream(gf3_ctx *ctx, const void *d_r, int64_t n,
                     void *d_work, double *d_corr_or_null, void *stream);
 
 /*
- * How gf3_sync_stream evaluates the matched filter.  Screened: every lag is first evaluated in fp32 with a proven
+ * How the stream-mode sync evaluates the matched filter.  Screened: every lag is first evaluated in fp32 with a proven
  * error bound; only the lags that the bound cannot exclude (a few around every chirp) are re-evaluated as fp64 dot
  * products, and the reference's rule (global maximum, threshold, extremum test) is applied to those fp64 values -- no
  * decision rests on an fp32 number; streams on which the screen is not selective take the all-fp64 overlap-save.
@@ -173,12 +179,19 @@ int gf3_sync_stream(gf3_ctx *ctx, const void *d_r, int64_t n,
  * where the band-limited one applies (a chirp whose spectrum lives below 3/16 of the sample rate, as the reference's
  * 0-8 kHz sweep at 48 kHz does: the bins above are left out of the fp32 products and their norm joins the error
  * bound).  Calls that ask for d_corr are always all-fp64.
- * The mode and the info block below are plain fields of the context: set / read them from the thread that calls
- * gf3_sync_stream on that context.
+ *
+ * gf3_sync_stream_ex is gf3_sync_stream with the mode as an argument and the diagnostics as an output; it reads the
+ * context only, so any number of threads may call it on one context at once.
+ *   h_info4 (host, optional): path taken (0 screened, 1 fp64 after a non-selective screen, 2 fp64), cells (of 14 lags)
+ *   re-evaluated in fp64, cells among them that hold a candidate, candidates found.
  */
+int gf3_sync_stream_ex(const gf3_ctx *ctx, const void *d_r, int64_t n,
+                       int64_t *d_peaks, int64_t cap, int64_t *n_peaks,
+                       void *d_work, double *d_corr_or_null,
+                       int32_t mode, int64_t *h_info4_or_null, void *stream);
+/* legacy conveniences: the default mode gf3_sync_stream uses (the one field of a context that a call writes; an atomic
+ * int), and the h_info4 of the CALLING THREAD's last gf3_sync_stream / gf3_sync_stream_ex */
 int gf3_sync_stream_mode(gf3_ctx *ctx, int32_t mode);
-/* h_out4 (host): of the last gf3_sync_stream call: path (0 screened, 1 fp64 after a non-selective screen, 2 fp64),
- * cells (of 14 lags) re-evaluated in fp64, cells among them that hold a candidate, candidates found */
 int gf3_sync_stream_info(const gf3_ctx *ctx, int64_t *h_out4);
 /* tests: the fp32 screening pass alone.  d_p32 [n+Lc-1] float; d_blk [2*nblk] float: per block of *h_hop lags its
  * maximum, then the bound on |P32 - P| of its lags (nblk = ceil((n+Lc-1) / hop)) */

@@ -127,6 +127,8 @@ if mode == "hang-after-fail" and rank == 0:
     import time; time.sleep(600)
 if mode == "hang-after-fail" and rank == 1:
     sys.exit(5)
+if mode == "sleep":
+    import time; time.sleep(600)
 print("noise from rank", rank, file=sys.stderr)
 if rank == 0:
     print(json.dumps({"n_gpus": world, "argv": sys.argv[1:]}))
@@ -152,7 +154,102 @@ def test_spawn_ranks_env_rc_and_single_json_line(tmp_path):
     assert rc == 7
     t0 = time.monotonic()
     rc, lines = spawn_ranks([sys.executable, str(stub), "hang-after-fail"], 2, relay=got.append, grace_s=1.0)
-    assert rc != 0 and time.monotonic() - t0 < 60 and lines == []
+    assert rc == 5 and time.monotonic() - t0 < 60 and lines == []      # rank 1's own code, not rank 0's -15
+    # an exception in the parent (here: raised by the relay callback) leaves no rank process behind
+    import psutil
+    before = {c.pid for c in psutil.Process().children(recursive=True)}
+
+    def boom(line):
+        raise KeyboardInterrupt
+    with pytest.raises(KeyboardInterrupt):
+        def relay_then_interrupt(line):
+            got.append(line)
+        # the interrupt arrives in the waiting thread: simulate it with a poll interval hook
+        orig_sleep = time.sleep
+        calls = {"n": 0}
+
+        def sleep(dt):
+            calls["n"] += 1
+            if calls["n"] == 3:
+                raise KeyboardInterrupt
+            orig_sleep(dt)
+        time.sleep = sleep
+        try:
+            spawn_ranks([sys.executable, str(stub), "sleep"], 2, relay=relay_then_interrupt)
+        finally:
+            time.sleep = orig_sleep
+    orig = time.monotonic()
+    while time.monotonic() - orig < 10:
+        left = {c.pid for c in psutil.Process().children(recursive=True) if c.is_running() and c.status() != psutil.STATUS_ZOMBIE} - before
+        if not left:
+            break
+        time.sleep(0.1)
+    assert not left, left
+
+
+WORKER8 = r'''
+import os, sys
+sys.path.insert(0, os.environ["GF3_ROOT"])
+import torch
+from gf3_audio_modem_amd import dist as gd
+rank, world, local = gd.init_from_env(backend="gloo")
+assert world == 8
+F_local, chunks, row = 64, 8, 12                  # 8 ranks x 8 chunks of 8 frames
+Fc = F_local // chunks
+mine = gd.cyclic_frame_index(rank, world, F_local, chunks)           # global frame numbers of this rank's rows
+# row of global frame g, decoded by rank r as its local frame l: tagged with all three
+def tag(g, r, l):
+    t = torch.zeros((len(g), row), dtype=torch.uint8)
+    t[:, 0] = r
+    t[:, 1] = l % 256
+    t[:, 2] = (g // 256) % 256
+    t[:, 3] = g % 256
+    t[:, 4:] = ((g[:, None] * 7 + torch.arange(row - 4)[None, :]) % 251).to(torch.uint8)
+    return t
+local_rows = tag(mine, rank, torch.arange(F_local))
+out = torch.empty((world * F_local, row), dtype=torch.uint8)
+og = gd.OverlappedGather(out, F_local, chunks)
+for c in range(chunks):
+    og.chunk_done(c, local_rows[c * Fc:(c + 1) * Fc].contiguous())
+og.finish()
+# EVERY rank checks the FULL order: row g of the gathered array is global frame g, decoded by the rank and at the
+# local position the block-cyclic map says
+want = torch.empty_like(out)
+for r in range(world):
+    idx = gd.cyclic_frame_index(r, world, F_local, chunks)
+    want[idx] = tag(idx, r, torch.arange(F_local))
+assert torch.equal(out, want)
+g = torch.arange(world * F_local)
+assert torch.equal(out[:, 2].long() * 256 + out[:, 3].long(), g)                       # global frame order
+c_of = g // (world * Fc); r_of = (g % (world * Fc)) // Fc; i_of = g % Fc
+assert torch.equal(out[:, 0].long(), r_of) and torch.equal(out[:, 1].long(), c_of * Fc + i_of)
+# ... and the literal single all-gather (chunks = 1) gives the contiguous-shard order
+out1 = torch.empty((world * F_local, row), dtype=torch.uint8)
+og1 = gd.OverlappedGather(out1, F_local, 1)
+og1.chunk_done(0, local_rows)
+og1.finish()
+assert torch.equal(out1[rank * F_local:(rank + 1) * F_local], local_rows)
+assert torch.equal(out1[:, 0].long(), torch.arange(world).repeat_interleave(F_local))
+gd.barrier()
+import torch.distributed as dist
+dist.destroy_process_group()
+if rank == 0:
+    print("all 8 ranks agree")
+'''
+
+
+def test_overlapped_gather_world_size_8_gloo(tmp_path):
+    """BASELINE config 4's collective at its real world size on CPU: 8 ranks x 8 chunks through OverlappedGather
+    (one all_gather_into_tensor per chunk) started by spawn_ranks; rows are tagged with (rank, local frame, global
+    frame) and EVERY rank checks the whole gathered order against cyclic_frame_index."""
+    from gf3_audio_modem_amd.dist import spawn_ranks
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8)
+    env = dict(os.environ, GF3_ROOT=ROOT, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    got = []
+    rc, lines = spawn_ranks([sys.executable, str(script)], 8, env=env, relay=got.append, grace_s=5.0)
+    assert rc == 0, lines
+    assert [l for l in lines if not l.startswith("[Gloo]")] == ["all 8 ranks agree"], lines    # (gloo announces its peers on stdout)
 
 
 def test_bench_parent_launches_ranks_without_touching_the_gpu(tmp_path, monkeypatch):

@@ -1017,3 +1017,52 @@ def test_new_abi_error_paths():
         eng.equalise_known_h(x, [0], np.ones(5000))
     eq, bits, idx = eng.equalise_known_h(x, [], np.ones(3))                    # no symbols: nothing to do
     assert eq.shape[0] == 0
+
+
+def test_two_threads_two_streams_share_one_context():
+    """include/gf3rx.h: no call writes into a context, so concurrent calls on one context are safe.  Two host threads,
+    each on its own HIP stream, run stream sync (different per-call modes) + demod on different inputs through ONE
+    engine; each must get exactly what the same calls give alone, its own diagnostics, and its own error text.
+    (Run once: it checks results; it is not a stress loop.)"""
+    import threading
+    g = load("g2_n4096_qpsk")
+    p = params_of(g)
+    eng = engine_for(p)
+    xa = torch.from_numpy(g["r"]).cuda()
+    xb = torch.cat([torch.zeros(777, dtype=torch.float64, device="cuda"), 0.5 * xa])   # another stream: shifted, scaled
+
+    def work(x, mode):
+        peaks, info = eng.sync_stream(x, mode=mode, want_info=True)
+        bits = eng.demod_frames(x, (peaks + 2)[:-1])["bits"]
+        return peaks.cpu().numpy(), bits.cpu().numpy(), info
+
+    alone = [work(xa, 1), work(xb, 2)]
+    assert np.array_equal(alone[0][0], g["peaks"]) and np.array_equal(alone[1][0], g["peaks"] + 777)
+    assert alone[0][2]["path"] == 2 and alone[1][2]["path"] in (0, 1)
+    got, errs, texts = [None, None], [None, None], [None, None]
+    go = threading.Barrier(2)
+
+    def run(i, x, mode):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                go.wait()
+                for _ in range(3):
+                    got[i] = work(x, mode)
+                    assert eng.sync_stream_info() == got[i][2]                 # this thread's own last call
+                if i == 0:                                                     # a failing call in ONE thread ...
+                    with pytest.raises(Exception) as ei:
+                        eng.sync_stream(x, cap=1, mode=mode)
+                    texts[0] = str(ei.value)
+                else:
+                    texts[1] = eng.lib.gf3_last_error(eng._h).decode()         # ... leaves the other's error text alone
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:                                             # noqa: BLE001 (reported below)
+            errs[i] = e
+
+    th = [threading.Thread(target=run, args=(0, xa, 1)), threading.Thread(target=run, args=(1, xb, 2))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert errs == [None, None], errs
+    for i in range(2):
+        assert np.array_equal(got[i][0], alone[i][0]) and np.array_equal(got[i][1], alone[i][1]) and got[i][2] == alone[i][2]
+    assert "exceed capacity" in texts[0] and "exceed capacity" not in texts[1]
