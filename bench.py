@@ -185,18 +185,93 @@ def cpu_baseline(cfg, rows_dev, payload_dev, window, target_s):
                       f"(NumPy restatement of OFDM.py, 1 thread), {dt:.1f} s, payload recovered: {ok}"}
 
 
-def _event_ms(fn, reps, warm=2):
-    """mean HIP-event time of `fn` (one launch on the current stream) over `reps` launches, in ms"""
+def _pool_stream(job):
+    """worker: oracle.receive on one whole stream (stream-mode sync + demod) -> number of decoded bits"""
+    from oracle import gf3_oracle as orc
+    r, pk = job
+    return int(len(orc.receive(r, orc.RxParams(**pk))["bits"]))
+
+
+def _config1_stream():
+    """BASELINE config 1 regenerated from the seed the g1b fixture records: 64 QPSK frames, N=1024, CP=128 (oracle.tx_stream
+    rebuilds the reference's transmit() stream bit for bit, tests/test_oracle_golden.py)."""
+    from oracle import gf3_oracle as orc
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g1b_config1_64f.npz"))
+    pts, bt = orc.qpsk_table()
+    pk = dict(N=int(g["N"]), CP=int(g["CP"]), P=int(g["P"]), D=int(g["D"]), lo=int(g["lo"]), hi=int(g["hi"]),
+              const_points=pts, const_bits=bt, known_bits=g["known_bits"])
+    p = orc.RxParams(**pk)
+    F = int(g["F"])
+    payload = np.random.RandomState(20261003).randint(0, 2, F * p.D * p.C * p.mu)
+    r = orc.tx_stream(payload, g["fill"], p, gaps=g["gaps"], lead=int(g["lead"]), tail=int(g["tail"]))
+    return r, pk, payload, "BASELINE config 1: 64 QPSK frames, N=1024 CP=128 P=2 D=8, one stream, noiseless"
+
+
+def _config3_stream(F=24):
+    """A 24-packet slice of BASELINE config 3: 16-QAM, N=4096 CP=512, through the measured 30-tap channel + noise."""
+    from scipy.signal import lfilter
+    from oracle import gf3_oracle as orc
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g3_n4096_16qam_gr5.npz"))
+    pk = dict(N=int(g["N"]), CP=int(g["CP"]), P=int(g["P"]), D=8, lo=int(g["lo"]), hi=int(g["hi"]),
+              const_points=g["const_points"], const_bits=g["const_bits"].astype(np.int64), known_bits=g["known_bits"].astype(np.uint8))
+    p = orc.RxParams(**pk)
+    rs = np.random.RandomState(33)
+    payload = rs.randint(0, 2, F * p.D * p.C * p.mu)
+    r = orc.tx_stream(payload, g["fill"], p, gaps=rs.randint(0, 300, F), lead=50, tail=40)
+    r = lfilter(g["channel"], 1.0, r) + 2e-4 * rs.randn(len(r))
+    return r, pk, payload, f"{F}-packet slice of BASELINE config 3: 16-QAM, N=4096 CP=512 P=2 D=8, gr5channel.csv FIR + noise, one stream"
+
+
+def cpu_baseline_streams(pool, cores, target_s=4.0):
+    """the oracle on configs 1 and 3 next to config 2's -- whole-stream receive (matched filter over the
+    stream, global-max peak rule, demod), 1 thread, and all cores as `cores` independent copies of the stream at once
+    (the reference has no parallelism inside a stream)."""
+    from oracle import gf3_oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
+    out = {}
+    for key, make in (("cpu_baseline_config1", _config1_stream), ("cpu_baseline_config3", _config3_stream)):
+        r, pk, payload, what = make()
+        p = orc.RxParams(**pk)
+        ctx = threadpool_limits(limits=1) if threadpool_limits else None
+        try:
+            t = time.perf_counter(); res = orc.receive(r, p); t1 = time.perf_counter() - t       # (also the warm-up)
+            reps = int(max(1, min(50, target_s / t1)))
+            t = time.perf_counter()
+            for _ in range(reps):
+                res = orc.receive(r, p)
+            dt = (time.perf_counter() - t) / reps
+        finally:
+            if ctx is not None and hasattr(ctx, "unregister"):
+                ctx.unregister()
+        ber = float(np.mean(res["bits"] != payload)) if len(res["bits"]) == len(payload) else None
+        ent = {"value": len(r) / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+               "sample": f"{what}: {len(r)} samples through oracle.receive, mean of {reps} passes, {dt:.3f} s each, BER vs payload {ber}"}
+        if pool is not None:
+            jobs = [(r, pk)] * cores
+            pool.map(_pool_stream, jobs[: cores])                                                 # warm the workers
+            t = time.perf_counter(); pool.map(_pool_stream, jobs, chunksize=1); dta = time.perf_counter() - t
+            ent["all_cores"] = {"value": cores * len(r) / dta, "unit": "samples/s", "cores": cores,
+                                "sample": f"{cores} independent copies of the stream at once, one per process, {dta:.2f} s"}
+        out[key] = ent
+    return out
+
+
+def _event_ms(fn, reps=20, warm=3):
+    """SURVEY 8(d) protocol for the secondary legs: MEDIAN HIP-event time of `fn` (one launch on the current stream)
+    over `reps` >= 20 launches after `warm` = 3 untimed ones, in ms"""
     for _ in range(warm):
         fn()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in evs:
         a.record(); fn(); b.record()
     torch.cuda.synchronize()
-    return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
-def config5_rooflines(dev, log2_samples=28, log2_symbols=26, reps=5):
+def config5_rooflines(dev, log2_samples=28, log2_symbols=26, reps=20):
     """BASELINE config 5, sized past the 256 MB Infinity Cache so that the figure is an HBM figure: per N in
     {1024, 2048, 4096, 8192} ONE launch of rfft_kernel over 2^28 f32 samples (1 GiB in, 2.1 GB of complex128 bins
     out, > 0.3 ms), and one launch of the 64-QAM soft demapper over 2^26 symbols (1 GiB in, 1.6 GB of f32 LLRs out).
@@ -221,7 +296,7 @@ def config5_rooflines(dev, log2_samples=28, log2_symbols=26, reps=5):
         by = n_sym * (4 * N + 16 * (N // 2 + 1))
         out["roofline_rfft"][f"N{N}"] = {"kernel": f"rfft_kernel<{N // 2},f32>", "bound": "hbm", "achieved": by / ms / 1e6, "peak": HBM_PEAK_GBS,
                                          "unit": "GB/s", "frac": by / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": by,
-                                         "avg_launch_ms": ms, "transforms_per_launch": n_sym, "max_rel_err_vs_numpy_fft": err}
+                                         "avg_launch_ms": ms, "timing": "median of 20 launches after 3 warm-ups", "transforms_per_launch": n_sym, "max_rel_err_vs_numpy_fft": err}
         del X, off
         eng.close()
     del x
@@ -244,7 +319,7 @@ def config5_rooflines(dev, log2_samples=28, log2_symbols=26, reps=5):
     return out
 
 
-def demod_16qam_roofline(dev, args, reps=5):
+def demod_16qam_roofline(dev, args, reps=20):
     """The config-2 geometry with the 16-QAM Gray table: the bits-only table mode of the fused kernel
     (demod_kernel<2048,f32,MODE_SCAN>) over F distinct frame buffers, every bit checked.
     Algorithmic bytes: B_in M N + D C mu / 8 = 204 792 B per packet."""
@@ -274,29 +349,50 @@ def demod_16qam_roofline(dev, args, reps=5):
                                      "algorithmic_bytes_per_launch": by, "avg_launch_ms": ms, "payload_recovered": ok}}
 
 
-def stream_sync_roofline(dev, frames=4096):
+VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4      # 1 024 SIMDs, one wave64 VALU instruction per 4 cycles, 2.4 GHz
+
+
+def stream_sync_roofline(dev, frames=4096, pmc=None):
     """BASELINE config 3 (tools/config3.py): 4 096 16-QAM packets as ONE stream through the measured 30-tap channel,
-    stream-mode chirp sync with the reference's global-max / first-extremum / suppression rule, then demod.
-    Algorithmic bytes of the sync: B_in per sample in, 8 B per detected peak out."""
+    stream-mode chirp sync with the reference's global-max / first-extremum / suppression rule, then demod; median of
+    20 passes after 3 warm-ups.  The call is NOT memory-bound: the fp32 screen transforms every sample
+    twice, so the line is priced against fp32 VALU ISSUE (wave-instructions of one call, from the committed SQ
+    counter pass, x 4 cycles / 1 024 SIMDs / 2.4 GHz) and carries the HBM figure beside it -- B_in per sample in,
+    8 B per detected peak out -- and the time of the all-fp64 evaluation of the same convolution (mode 1)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("gf3_config3", os.path.join(ROOT, "tools", "config3.py"))
     tool = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tool)
     eng, cfg, channel = tool.make_engine()
     r, payload = tool.make_stream(eng, channel, frames)
-    res, starts, _ = tool.measure(eng, cfg, r, payload, reps=3)
+    res, starts, _ = tool.measure(eng, cfg, r, payload, reps=20, warm=3, fp64_reps=20)
     by = 4 * r.numel() + 8 * (frames + 1)
     t = res["sync_stream_s"]
-    out = {"roofline_stream_sync": {"kernel": "gf3_sync_stream (config 3: one 321 M-sample stream, 4 096 packets)", "bound": "hbm",
-                                    "achieved": by / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS,
-                                    "algorithmic_bytes_per_call": by, "call_ms": t * 1e3, "demod_ms": res["demod_s"] * 1e3,
+    insts = (pmc or {}).get("stream_sync_valu_wave_instructions_per_call")
+    traffic = (pmc or {}).get("stream_sync_hbm_bytes_per_call")
+    out = {"roofline_stream_sync": {"kernel": "gf3_sync_stream (config 3: one 321 M-sample stream, 4 096 packets; scr_ring_kernel + scr_refine_kernel + lists)",
+                                    "bound": "valu_f32",
+                                    "achieved": (insts / t / 1e9) if insts else None, "peak": VALU_PEAK_WAVE_INSTR_PER_S / 1e9,
+                                    "unit": "G wave-instr/s", "frac": (insts / t / VALU_PEAK_WAVE_INSTR_PER_S) if insts else None,
+                                    "valu_wave_instructions_per_call": insts,
+                                    "counter_source": "profiles/traffic_current.json (SQ_INSTS_VALU pass of this command; not measured in this run)" if insts else None,
+                                    "hbm": {"achieved": by / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS,
+                                            "algorithmic_bytes_per_call": by, "traffic": traffic},
+                                    "call_ms": t * 1e3, "fp64_path_ms": res["sync_stream_fp64_path_s"] * 1e3, "demod_ms": res["demod_s"] * 1e3,
+                                    "timing": res["timing"],
                                     "samples_per_s_sync_plus_demod": res["samples_per_s"], "ber_vs_payload": res["ber"],
                                     "sync_offsets_exact": res["sync_offsets_as_expected_plus1"],
-                                    "sync_path": eng.sync_stream_info(),
-                                    "limiter": "fp32 VALU issue of the screening transforms (two waves per SIMD at 256 registers; clock not "
-                                               "throttled); measured HBM traffic 1.5 x the algorithmic bytes (DESIGN.md section 3.1, profiles/)"}}
+                                    "sync_path": res["sync_path"]}}
     eng.close()
     return out
+
+
+def rccl_version():
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:
+        return None
 
 
 def launch_ranks(n):
@@ -329,7 +425,15 @@ def main():
                          "through a one-rank RCCL group; a rehearsal of the multi-GPU path, not the headline number")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 rFFT / soft-demap roofline legs (N=1)")
     ap.add_argument("--no-stream", action="store_true", help="skip the config-3 stream-sync roofline leg (N=1)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-ingest (pinned, chunked H2D + stream receive) leg (N=1)")
+    ap.add_argument("--gather-algo", default=None, help="N>1: NCCL_ALGO for the all-gather (e.g. Ring, Tree, Direct), set before the "
+                    "process group exists, so that a scaling run can compare algorithms (SURVEY section 5) without a code change")
+    ap.add_argument("--gather-proto", default=None, help="N>1: NCCL_PROTO (e.g. Simple, LL, LL128)")
     args = ap.parse_args()
+    if args.gather_algo:
+        os.environ["NCCL_ALGO"] = args.gather_algo         # (inherited by the ranks launch_ranks starts)
+    if args.gather_proto:
+        os.environ["NCCL_PROTO"] = args.gather_proto
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))        # the children run the rest of main() with WORLD_SIZE set
     if args.frames <= 0:
@@ -450,12 +554,13 @@ def main():
                 for r in range(world):
                     idx = gd.cyclic_frame_index(r, world, F, self.chunks).to(dev)
                     gather_ok = gather_ok and bool(checksum(self.gathered[idx]) == sums[r])
-                flag = torch.tensor([1.0 if gather_ok else 0.0, float(bit_errors == 0), float(sync_ok)], dtype=torch.float64, device=dev)
+                flag = torch.tensor([1.0 if gather_ok else 0.0, float(sync_ok)], dtype=torch.float64, device=dev)
                 tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)           # every rank's verdict, not rank 0's alone
                 gather_ok = bool(flag[0].item() == 1.0)
-                if flag[1].item() != 1.0 and bit_errors == 0:
-                    bit_errors = -1                                       # some other rank saw bit errors
-                sync_ok = bool(flag[2].item() == 1.0)
+                sync_ok = bool(flag[1].item() == 1.0)
+                be = torch.tensor([bit_errors], dtype=torch.int64, device=dev)
+                tdist.all_reduce(be, op=tdist.ReduceOp.SUM)             # bit errors of ALL ranks' frames, each checked by its own rank
+                bit_errors = int(be.item())
             return bit_errors, sync_ok, gather_ok
 
     run = Run(args.chunks)
@@ -500,14 +605,16 @@ def main():
     bytes_demod = Fl * (b_in * cfg.M * cfg.N + eng.bytes_per_frame)                     # 200 700 B/frame
     bytes_sync = Fl * (b_in * (cfg.chirp_length + args.window - 1) + 8)
     ach = bytes_demod / t_demod / 1e9
-    traffic = None
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/profile_round.sh ->
+    # tools/collect_profiles.py -> profiles/traffic_current.json): a constant read from a file, NOT measured by this run
+    traffic, pmc = None, {}
     tfile = os.path.join(ROOT, "profiles", "traffic_current.json")
     if os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("demod_kernel_bytes_per_launch_at_F", {}).get(str(Fl))   # same launch size only
+            pmc = json.load(open(tfile))
+            traffic = pmc.get("demod_kernel_bytes_per_launch_at_F", {}).get(str(Fl))   # same launch size only
         except Exception:
-            traffic = None
-
+            traffic, pmc = None, {}
     extra = {}
     if world == 1 and not multi:
         del run.bits
@@ -515,7 +622,7 @@ def main():
             extra.update(demod_16qam_roofline(dev, args))
             extra.update(config5_rooflines(dev))
         if not args.no_stream:
-            extra.update(stream_sync_roofline(dev))
+            extra.update(stream_sync_roofline(dev, pmc=pmc))
 
     if rank == 0:
         from gf3_audio_modem_amd import _lib
@@ -538,15 +645,22 @@ def main():
                        "frames_per_gpu": F, "frames_total": total_frames, "samples_per_frame": args.stride, "sample_storage": "f32",
                        "sync_window_lags": args.window, "parallelism": f"frames sharded over {world} GPU(s), "
                        f"packed bits all-gathered in {chunks} chunk(s) under compute" if multi else "single GPU"},
-            "ber": bit_errors / (F * cfg.bits_per_frame), "bit_errors": bit_errors, "frames_checked": F * world if multi else F, "sync_exact": sync_ok,
+            "ber": bit_errors / (total_frames * cfg.bits_per_frame), "bit_errors": bit_errors,
+            "frames_checked": total_frames, "frames_checked_note": "every rank compares its own frames with their payload; the counts are summed over ranks" if multi else None,
+            "sync_exact": sync_ok,
             "gather_exact": gather_ok, "ranks_in_group": (torch.distributed.get_world_size() if multi else 1),
             "single_gather": single,
+            "collective": ({"backend": torch.distributed.get_backend(), "library_version": rccl_version(),
+                            "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"),
+                            "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))},
+                            "note": "algorithm / protocol are RCCL's own choice unless NCCL_ALGO / NCCL_PROTO are set "
+                                    "(--gather-algo / --gather-proto)"} if multi else None),
             "library": {"version": ver, "source_sha16": src},
             "roofline": {"kernel": "demod_kernel<2048,f32,MODE_QPSK>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/traffic_current.json (FETCH_SIZE + WRITE_SIZE passes of this command under rocprofv3, "
+                                           "gfx950-corrected; a committed constant, not measured in this run)" if traffic else None,
                          "algorithmic_bytes_per_launch": bytes_demod, "avg_launch_ms": t_demod * 1e3,
-                         "limiter": "package power (cap 1.4 kW): energy dominated by the fp64 operation count of the "
-                                    "transforms (DESIGN.md section 8)",
                          "package_power_w_sustained": power_w,
                          "energy_nJ_per_sample": (power_w * dt / args.steps / (world * n_samples) * 1e9 * world) if power_w else None},
             "roofline_sync": {"kernel": "corr_kernel<1024,f32> (15 x 2048-point transforms per packet)", "bound": "hbm", "achieved": bytes_sync / t_sync / 1e9,
@@ -559,6 +673,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             if pool is not None:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pool, cores, cfg, big, payload, args.window)
+            out.update(cpu_baseline_streams(pool, cores))
         print(json.dumps(out))
     if pool is not None:
         pool.close(); pool.join()

@@ -26,6 +26,7 @@ class Gf3Config(C.Structure):
 
 _SIGS = {
     "gf3_version": (C.c_char_p, []),
+    "gf3_source_hash": (C.c_char_p, []),
     "gf3_ctx_create": (C.c_int, [C.POINTER(Gf3Config), C.POINTER(C.c_void_p)]),
     "gf3_ctx_destroy": (None, [C.c_void_p]),
     "gf3_last_error": (C.c_char_p, [C.c_void_p]),
@@ -45,6 +46,12 @@ _SIGS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "gf3_sync_stream_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, c_i64_p,
                                      C.c_void_p, C.c_void_p, C.c_int32, c_i64_p, C.c_void_p]),
+    "gf3_sync_chunk_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "gf3_sync_chunk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int64, c_i64_p, C.c_void_p, C.c_void_p]),
+    "gf3_sync_decide_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "gf3_sync_decide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                  c_i64_p, C.c_void_p, C.c_void_p]),
     "gf3_sync_stream_mode": (C.c_int, [C.c_void_p, C.c_int32]),
     "gf3_sync_stream_info": (C.c_int, [C.c_void_p, c_i64_p]),
     "gf3_debug_stream_screen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
@@ -73,15 +80,18 @@ def load():
     path = lib_path()
     from . import build as _build
     if not os.environ.get("GF3_LIB") and _build.stale():
-        # missing, or older than gf3rx.hip / gf3rx_device.h / gf3rx.h (content hash): compile it here if the ROCm
-        # toolchain is present (same gfx950 build as __graft_entry__.build(), temp file + rename under a lock);
-        # otherwise fail loudly -- kernels that do not match the source must not run, and there is no other
-        # implementation to fall back to
+        # missing, or built from other sources than gf3rx.hip / gf3rx_device.h / gf3rx_screen.h / gf3rx.h as they are now
+        # (the library carries the SHA-256 of what it was built from): compile it here if the ROCm toolchain is present
+        # (same gfx950 build as __graft_entry__.build(), temp file + rename under a lock); otherwise fail loudly --
+        # kernels that do not match the source must not run, and there is no other implementation to fall back to
         if _build.have_compiler():
             _build.build_lib()
         elif os.path.exists(path):
-            raise ImportError(f"{path} does not match its sources (hash {_build.built_hash()} != {_build.source_hash()}) "
-                              "and no hipcc is available to rebuild it")
+            have = _build.built_hash()
+            why = ("carries no source stamp (built by hand or by an older checkout)" if have is None
+                   else f"was built from other sources (stamp {have[:16]}..., sources now {_build.source_hash()[:16]}...)")
+            raise ImportError(f"{path} {why} and no hipcc is available to rebuild it; "
+                              "set GF3_LIB=<path> to load a library of your own choosing")
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is not built. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -99,4 +109,4 @@ def build_id():
     """(library version string, first 16 hex digits of the source hash it was built from) for bench records."""
     from . import build as _build
     lib = load()
-    return lib.gf3_version().decode(), (_build.built_hash() or "unknown")[:16]
+    return lib.gf3_version().decode(), lib.gf3_source_hash().decode()[:16]

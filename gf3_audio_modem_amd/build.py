@@ -1,13 +1,15 @@
 """Build libgf3rx.so in-tree with hipcc for gfx950 (no JIT cache: the built
 library travels to the GPU box with the repo snapshot).
 
-Staleness is decided by content, not by time stamps (a snapshot copy does not keep them): the build writes the
-SHA-256 of its sources next to the library, and `stale()` compares it with the sources as they are now.  Builds
+Staleness is decided by content, not by time stamps (a snapshot copy does not keep them): the build compiles the
+SHA-256 of its sources and flags INTO the library (`gf3_source_hash()`; no side file that packaging could lose), and
+`stale()` compares it with the sources as they are now, reading the stamp out of the file without loading it.  Builds
 go to a temporary file that is renamed into place under a file lock, so N ranks that all find the library stale
 compile once and never dlopen a half-written file."""
 import fcntl
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -17,7 +19,7 @@ SRC = [os.path.join(HERE, "csrc", "gf3rx.hip")]
 DEPS = SRC + [os.path.join(HERE, "csrc", "gf3rx_device.h"), os.path.join(HERE, "csrc", "gf3rx_screen.h"),
               os.path.join(ROOT, "include", "gf3rx.h")]
 LIB = os.path.join(HERE, "lib", "libgf3rx.so")
-STAMP = LIB + ".srchash"
+MARKER = b"GF3_SRC_HASH="
 # -fno-slp-vectorize: LLVM otherwise pairs the screening kernel's fp32 complex arithmetic into v_pk_* instructions,
 # which issue at half rate on gfx950 and need register shuffles (scr_ols_kernel 3.0 -> 2.6 ms without them; the fp64
 # kernels, which have no packed form, are unchanged)
@@ -38,11 +40,15 @@ def source_hash():
     return h.hexdigest()
 
 
-def built_hash():
+def built_hash(path=None):
+    """The source hash compiled into the library (None: no library, or one without a stamp -- built by hand / by an
+    older checkout)."""
     try:
-        return open(STAMP).read().strip()
+        blob = open(path or LIB, "rb").read()
     except OSError:
         return None
+    m = re.search(MARKER + rb"([0-9a-f]{64})", blob)
+    return m.group(1).decode() if m else None
 
 
 def stale():
@@ -65,7 +71,7 @@ def build_lib(force=False, verbose=False):
                 return LIB
             want = source_hash()
             tmp = f"{LIB}.tmp.{os.getpid()}"
-            cmd = [hipcc] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-o", tmp] + SRC
+            cmd = [hipcc] + FLAGS + [f'-DGF3_SRC_HASH="{want}"', "-I" + os.path.join(ROOT, "include"), "-o", tmp] + SRC
             if verbose:
                 print(" ".join(cmd))
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -74,9 +80,6 @@ def build_lib(force=False, verbose=False):
                     os.remove(tmp)
                 raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
             os.replace(tmp, LIB)
-            with open(STAMP + ".tmp", "w") as fh:
-                fh.write(want + "\n")
-            os.replace(STAMP + ".tmp", STAMP)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB

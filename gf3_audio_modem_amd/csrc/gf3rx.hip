@@ -11,7 +11,6 @@
 
 #include "gf3rx.h"
 #include "gf3rx_device.h"
-#include "gf3rx_fft16.h"
 #include "gf3rx_screen.h"
 
 // ============================================================================
@@ -195,7 +194,7 @@ GF3_DEV int scan_table(cplx e, const double* cre, const double* cim, int M) {
 // rounding of either evaluation.
 GF3_DEV uint32_t uni_axis(double x, double lo, double inv, int n, unsigned long long pack, bool& clear) {
     const double t = (x - lo) * inv;
-    const double r = fmin(fmax(rint(t), 0.0), (double)(n - 1));
+    const double r = fmin(fmax(rint(t), 0.0), (double)(n > 1 ? n - 1 : 0));     // (never negative: r indexes `pack`)
     const double d = fabs(t - r);
     clear = (d < 1e300) && !(fabs(0.5 - d) < 1e-9);
     return (uint32_t)(pack >> (8 * (int)r)) & 0xffu;
@@ -548,11 +547,13 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
                     if (ps >= 0 && a.eq) a.eq[((int64_t)f * D + l) * C + ps] = e;
                 }
                 if (ps >= 0) {
-                    bool ci, cq;
-                    const uint32_t li = uni_axis(e.x, a.ug.loI, a.ug.invI, a.ug.nI, a.ug.packI, ci);
-                    const uint32_t lq = uni_axis(e.y, a.ug.loQ, a.ug.invQ, a.ug.nQ, a.ug.packQ, cq);
-                    lab_l[ps] = (uint8_t)(li | lq);
-                    if (!(ci && cq && a.ug.nI > 0)) unclear |= 1u << s;
+                    if (a.ug.nI > 0) {                                     // (wave-uniform) a grid with equally spaced levels
+                        bool ci, cq;
+                        const uint32_t li = uni_axis(e.x, a.ug.loI, a.ug.invI, a.ug.nI, a.ug.packI, ci);
+                        const uint32_t lq = uni_axis(e.y, a.ug.loQ, a.ug.invQ, a.ug.nQ, a.ug.packQ, cq);
+                        lab_l[ps] = (uint8_t)(li | lq);
+                        if (!(ci && cq)) unclear |= 1u << s;
+                    } else unclear |= 1u << s;                             // any other table: every data carrier takes the literal scan
                 }
             }
             // Rare path, one marked carrier at a time (no unrolling: nothing of the transform is live here, and the
@@ -596,15 +597,6 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 #endif
 #ifndef GF3_CORR_PP
 #define GF3_CORR_PP true
-#endif
-#ifndef GF3_CORR16_PROBE
-#define GF3_CORR16_PROBE 0
-#endif
-#ifndef GF3_CORR16_LATE
-#define GF3_CORR16_LATE 0     /* 1: the next segment's samples are fetched into registers under the last multiply-accumulate */
-#endif
-#ifndef GF3_CORR16
-#define GF3_CORR16 1          /* plans of 2048-point transforms run corr16_kernel (one wave, 16 points per thread) */
 #endif
 template <int NC, int DT>
 __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_kernel(CorrArgs a) {
@@ -737,163 +729,6 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         }
     }
     first = block_min_i(first, (int*)(scratch + 16));
-    if (tid == 0) {
-        const bool found = first != 0x7fffffff;
-        a.starts[b] = found ? (s0 + first + a.Lc) : -1;
-        if (a.peak) a.peak[b] = found ? y[first] : 0.0;
-    }
-}
-
-// ============================================================================
-// The same correlator on the one-wave, 16-points-per-thread transform (gf3rx_fft16.h) for plans of 2048-point
-// transforms (NC = 1024: the frames plan of every N = 4096 geometry): one search window per 64-thread workgroup,
-// two LDS exchanges per transform instead of three, and no s_barrier at all -- the eight waves of a CU work on
-// eight different windows and drift apart.  Same arguments, same results to rounding (the transform's passes are
-// 16 . 16 . 4 instead of 8 . 8 . 4 . 4).
-// ============================================================================
-template <int DT>
-__global__ __launch_bounds__(64, 2) void corr16_kernel(CorrArgs a) {
-    extern __shared__ double2 smem[];
-    constexpr int NC = 1024, T = 64;
-    cplx* lds = smem;
-    const int tid = threadIdx.x;
-    const int64_t b = blockIdx.x;
-    const int64_t s0 = b * a.stride + a.win_lo;
-    const int W = a.W;
-    F16Tw ft;
-    ft.init(tid, a.t.tw, a.t.twn);
-    cplx acc[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc[s] = cmk(0.0, 0.0);
-    double accDC = 0.0, accNy = 0.0;
-    // samples of a segment that reach valid lags, rounded up to whole strided loads (128 samples): a load is then
-    // either wholly wanted or wholly zero, with no per-lane predicate (the extra samples only reach lags >= W)
-    const int nfull = (a.Lp + a.Wmax - 1 + 2 * T - 1) / (2 * T);
-    typedef typename RawT<DT>::E E;
-    RawPair<DT> nxt[16];
-    auto fetch = [&](int q) {
-        const int64_t seg = s0 + (int64_t)q * a.Lp;
-        const E* base = (const E*)a.in + seg;                            // wave-uniform
-        const unsigned t2 = 2u * (unsigned)tid;
-        if (seg >= 0 && seg + 2 * NC <= a.n_in) {                        // (uniform) the segment lies inside the buffer
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { if (r < nfull) nxt[r].load_u(base, t2 + (unsigned)(2 * T * r)); else nxt[r].zero(); }
-        } else {                                                         // buffer edges: clamped addresses, selects
-            const int64_t last = a.n_in - 1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t i0 = seg + 2 * T * r + 2 * tid, i1 = i0 + 1;
-                const int64_t c0 = i0 < 0 ? 0 : (i0 > last ? last : i0), c1 = i1 < 0 ? 0 : (i1 > last ? last : i1);
-                const E e0 = ((const E*)a.in)[c0], e1 = ((const E*)a.in)[c1];
-                nxt[r].v.a = (r < nfull && c0 == i0) ? e0 : (E)0;
-                nxt[r].v.b = (r < nfull && c1 == i1) ? e1 : (E)0;
-            }
-        }
-    };
-    // One-register prefetch of a segment into L2: lane l touches the 128-byte line l of the segment's 64 (f32) or fewer.
-    // The 32 registers of the real loads are then only needed from the last multiply-accumulate of a transform to the
-    // start of the next one, when nothing else of the transform is live, and those loads hit L2.
-    auto touch = [&](int q) {
-        const int64_t seg = s0 + (int64_t)q * a.Lp;
-        int64_t i = seg + (int64_t)tid * (128 / (int)sizeof(E));
-        i = i < 0 ? 0 : (i >= a.n_in ? a.n_in - 1 : i);
-        const float x = (float)((const E*)a.in)[i];
-        asm volatile("" :: "v"(x));                                      // (keeps the load; its value is not used)
-    };
-#if GF3_CORR16_LATE || GF3_CORR16_PROBE
-    fetch(0);
-    if (a.Q > 1) touch(1);
-#else
-    touch(0);
-    if (a.Q > 1) touch(1);
-#endif
-    cplx v[16], z0;
-    for (int q = 0; q < a.Q; ++q) {
-        const cplx* Hq = a.Hq + (int64_t)q * (NC + 1);
-#if !GF3_CORR16_LATE && !GF3_CORR16_PROBE
-        fetch(q);                                                        // (L2 hits: touched a transform ago)
-#endif
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = nxt[r].get();
-#if GF3_CORR16_PROBE     /* timing probe, WRONG results: four accumulators instead of sixteen, so that the early register prefetch fits */
-        if (q + 1 < a.Q) fetch(q + 1);
-#define ACC16(i) acc[(i) & 3]
-#else
-#define ACC16(i) acc[i]
-#endif
-        if (q + 2 < a.Q) touch(q + 2);
-        ft.refresh();
-        f16_passes12(v, lds, ft, tid);
-        // the spectrum in two halves of eight slots, each multiplied into the accumulators at once (four fma per slot)
-        {
-            cplx o[8], hq[8];
-            rfft16_half<true, 0>(o, lds, ft, tid, z0);                   // slots hold 2 X: undone by `inv` below
-#pragma unroll
-            for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec16::bin(tid, s)];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) ACC16(s) = cfma(o[s], cconj(hq[s]), ACC16(s));
-        }
-        {
-            cplx o[8], hq[8];
-            rfft16_half<true, 1>(o, lds, ft, tid, z0);
-#if GF3_CORR16_LATE
-            wave_lds_fence();
-            if (q + 1 < a.Q) fetch(q + 1);
-#endif
-#pragma unroll
-            for (int s = 0; s < 8; ++s) hq[s] = Hq[Spec16::bin(tid, 8 + s)];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) ACC16(8 + s) = cfma(o[s], cconj(hq[s]), ACC16(8 + s));
-        }
-        if (tid == 0) {
-            accDC += (z0.x + z0.y) * Hq[0].x;
-            accNy += (z0.x - z0.y) * Hq[NC].x;
-        }
-    }
-    // ---- inverse real FFT of the accumulated Hermitian spectrum Y (construction as in corr_kernel)
-    wave_lds_fence();
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int k = Spec16::bin(tid, 2 * p);
-        const cplx wk = p < 4 ? Spec<1024>::pair_tw(tid, p, ft.wb) : Spec<1024>::pair_tw(1, p - 4, ft.wb2());
-        const cplx A = acc[2 * p];
-        const cplx B = cconj(acc[2 * p + 1]);
-        const cplx E2 = cscale(cadd(A, B), 0.5);
-        const cplx Op = cmul_conj(cscale(csub(A, B), 0.5), wk);          // * exp(+2 pi i k/N)
-        const cplx Zk = cadd(E2, mul_posi(Op));
-        const cplx Zm = cadd(cconj(E2), mul_posi(cconj(Op)));
-        lds[k] = cconj(Zk);
-        if (Spec16::live(tid, 2 * p + 1)) lds[NC - k] = cconj(Zm);
-    }
-    if (tid == 0) {
-        const double E2 = accDC + accNy, Op = accDC - accNy;
-        lds[0] = cmk(E2, -Op);
-    }
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = lds[tid + r * T];
-    ft.refresh();
-    f16_fft(v, lds, ft, tid);
-    const double inv = 0.5 / (double)NC;
-    for (int i = tid; i < NC; i += T) { const cplx z = lds[i]; lds[i] = cmk(z.x * inv, -z.y * inv); }
-    wave_lds_fence();
-    const double* y = (const double*)lds;
-
-    // ---- peak rule on the window (OFDM.py:359-361), as corr_kernel; the workgroup is one wave
-    double mx = -INFINITY;
-    for (int j = tid; j < W; j += T) mx = fmax(mx, y[j]);
-    mx = wave_max(mx);
-    int first = 0x7fffffff;
-    const bool filt = mx > 0.0 && a.thresh > 0.0 && mx < INFINITY && a.thresh < INFINITY;
-    const double lim = filt ? a.thresh * mx * (1.0 - 1e-6) : -INFINITY;
-    for (int j = 1 + tid; j < W - 1; j += T) {
-        const double y0 = y[j];
-        if (!(y0 < lim)) {
-            const double pm1 = y[j - 1] / mx, p0 = y0 / mx, pp1 = y[j + 1] / mx;
-            if (((p0 - pm1) * (pp1 - p0) <= 0.0) && (p0 > a.thresh)) first = min(first, j);
-        }
-    }
-    first = wave_min_i(first);
     if (tid == 0) {
         const bool found = first != 0x7fffffff;
         a.starts[b] = found ? (s0 + first + a.Lc) : -1;
@@ -1741,7 +1576,9 @@ static int build_screen_plan(gf3_ctx* c) {
     }
     // (selective only when the chirp lives below the cut: the reference's 0-8 kHz sweep at 48 kHz drops ~1.3 %)
     sp.ring = Q <= GF3_SCR_RQ && hout_sum <= 0.05 * hall_sum;
-    if (const char* e = getenv("GF3_SCR_R")) sp.R_forced = atoi(e);       // (tuning aid: output blocks per workgroup)
+#ifdef GF3_DEV_BUILD
+    if (const char* e = getenv("GF3_SCR_R")) sp.R_forced = atoi(e);       // (tuning aid of developer builds only: output blocks per workgroup)
+#endif
     std::vector<float> tw(2 * NC), twn(2 * (NC / 2 + 1));
     const long double PI2 = 6.283185307179586476925286766559005768L;
     for (int m = 0; m < NC; ++m) { const long double a = -PI2 * m / NC; tw[2 * m] = (float)cosl(a); tw[2 * m + 1] = (float)sinl(a); }
@@ -1758,6 +1595,15 @@ static int build_screen_plan(gf3_ctx* c) {
 }
 
 extern "C" const char* gf3_version(void) { return GF3RX_VERSION; }
+
+// SHA-256 of the sources and flags this binary was built from (gf3_audio_modem_amd/build.py passes it in; "unknown" for a
+// build made by hand).  The loader compares it with the sources as they are now -- the library carries its own stamp,
+// no side file -- and finds it by the marker without loading the library.
+#ifndef GF3_SRC_HASH
+#define GF3_SRC_HASH "unknown"
+#endif
+extern "C" const char gf3_src_hash_marker[] = "GF3_SRC_HASH=" GF3_SRC_HASH;
+extern "C" const char* gf3_source_hash(void) { return gf3_src_hash_marker + 13; }
 
 extern "C" const char* gf3_last_error(const gf3_ctx*) { return g_err; }
 
@@ -2205,16 +2051,6 @@ static hipError_t run_corr(const gf3_ctx* c, const CorrPlan& pl, const CorrArgs&
     const int NCp = pl.NC;
     const size_t lds = (GF3_CORR_PP ? fft_lds_bytes(NCp) : (size_t)(NCp + NCp / 8) * sizeof(cplx)) + 32 * sizeof(double);
     hipError_t e = hipSuccess;
-#if GF3_CORR16
-    if (NCp == 1024 && a.dt != DT_F64) {              // one-wave transforms (f64 samples: no room for the prefetch)
-        const size_t lds16 = (size_t)1024 * sizeof(cplx);
-        if (a.dt == DT_F32) return launch((corr16_kernel<DT_F32>), grid, 64, lds16, st, a);
-#ifndef GF3_DEV_BUILD
-        if (a.dt == DT_I16) return launch((corr16_kernel<DT_I16>), grid, 64, lds16, st, a);
-        return launch((corr16_kernel<DT_U8>), grid, 64, lds16, st, a);
-#endif
-    }
-#endif
 #ifdef GF3_DEV_BUILD
     if (NCp == 1024) {
         if (a.dt == DT_F64) return launch((corr_kernel<1024, DT_F64>), grid, 128, lds, st, a);
@@ -2493,6 +2329,198 @@ extern "C" int gf3_sync_stream(gf3_ctx* c, const void* d_r, int64_t n, int64_t* 
                                int64_t* n_peaks, void* d_work, double* d_corr, void* stream) {
     if (!c) return fail(c, GF3_EINVAL, "gf3_sync_stream: bad argument");
     return gf3_sync_stream_ex(c, d_r, n, d_peaks, cap, n_peaks, d_work, d_corr, c->default_stream_mode.load(std::memory_order_relaxed), nullptr, stream);
+}
+
+// ============================================================================
+// Chunked stream sync: chirp_method (OFDM.py:356-372) on a stream that arrives piece by piece (host ingest, streams
+// longer than HBM) with the EXACT global rule.  The threshold of the reference is relative to the maximum of the WHOLE
+// stream (:359), which is only known at the end; so every piece keeps, next to the running maximum, the few lags that
+// could still pass whatever the final maximum turns out to be -- P[g] >= thresh * (maximum so far) * (1 - 1e-6); the
+// final maximum can only be larger -- together with the three raw fp64 values P[g-1], P[g], P[g+1] the rule looks at.
+// gf3_sync_decide then applies the rule literally (division by the maximum first, extremum test, threshold) to those
+// raw values, with the final maximum or, provisionally, with the maximum so far, and walks the suppression.
+// ============================================================================
+#define CK_THREADS 256
+__global__ __launch_bounds__(CK_THREADS) void ck_max_kernel(const double* __restrict__ P, int64_t lo, int64_t hi, double* part) {
+    __shared__ double scratch[16];
+    double mx = -INFINITY;
+    bool nan = false;
+    for (int64_t i = lo + (int64_t)blockIdx.x * CK_THREADS + threadIdx.x; i < hi; i += (int64_t)gridDim.x * CK_THREADS) {
+        const double v = P[i];
+        mx = fmax(mx, v);
+        nan = nan || !(v == v);
+    }
+    mx = block_max(mx, scratch);
+    const int anynan = __syncthreads_or(nan ? 1 : 0);                   // np.amax propagates NaN (OFDM.py:359)
+    if (threadIdx.x == 0) part[blockIdx.x] = anynan ? NAN : mx;
+}
+// run_max = amax(run_max, part[0..n)) with NumPy's NaN rule
+__global__ void ck_fold_max(const double* part, int n, double* run_max) {
+    __shared__ double scratch[16];
+    double mx = -INFINITY;
+    bool nan = false;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const double v = part[i]; mx = fmax(mx, v); nan = nan || !(v == v); }
+    mx = block_max(mx, scratch);
+    const int anynan = __syncthreads_or(nan ? 1 : 0);
+    if (threadIdx.x == 0) {
+        const double run = run_max[0];
+        run_max[0] = (anynan || !(run == run)) ? NAN : fmax(run, mx);
+    }
+}
+// pass 0 (offsets == nullptr): count per block; pass 1: write zeros-index g - 1 + lag_offset and the raw triple of every
+// listed lag g in [lo, hi), ascending
+__global__ __launch_bounds__(PK_THREADS) void ck_list_kernel(const double* __restrict__ P, int64_t lo, int64_t hi, const double* mxp, double thresh,
+                                                             int64_t lag_offset, int64_t* counts, const int64_t* offsets, int64_t* idx, double* val3) {
+    __shared__ int wsum[PK_THREADS / 64];
+    if (offsets && counts[blockIdx.x] == 0) return;
+    const double mx = mxp[0];
+    const bool filt = mx > 0.0 && thresh > 0.0 && mx < INFINITY && thresh < INFINITY;
+    const double lim = filt ? thresh * mx * (1.0 - 1e-6) : -INFINITY;   // (no positive finite maximum yet: every lag stays listed)
+    const int64_t base = lo + ((int64_t)blockIdx.x * PK_THREADS + threadIdx.x) * PK_ITEMS;
+    int c = 0;
+    unsigned flags = 0;
+#pragma unroll
+    for (int k = 0; k < PK_ITEMS; ++k)
+        if (base + k < hi && !(P[base + k] < lim)) { flags |= 1u << k; ++c; }
+    int x = c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < PK_THREADS / 64; ++w) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+    if (!offsets) { if (threadIdx.x == 0) counts[blockIdx.x] = total; return; }
+    int64_t o = offsets[blockIdx.x] + woff + (x - c);
+    for (int k = 0; k < PK_ITEMS; ++k)
+        if (flags & (1u << k)) {
+            const int64_t g = base + k;
+            idx[o] = g - 1 + lag_offset;
+            val3[3 * o] = P[g - 1]; val3[3 * o + 1] = P[g]; val3[3 * o + 2] = P[g + 1];
+            ++o;
+        }
+}
+// the reference's rule on the listed raw values (OFDM.py:359-361): p = P / max first, then
+// (p1 - p0)(p2 - p1) <= 0 and p1 > thresh; survivors compacted in order.  One workgroup.
+__global__ __launch_bounds__(1024) void ck_decide_kernel(const int64_t* idx, const double* val3, int64_t n, const double* mxp, double thresh,
+                                                         int64_t* cand, int64_t* total) {
+    __shared__ int wsum[16];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const double mx = mxp[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t b0 = 0; b0 < n; b0 += 1024) {
+        const int64_t i = b0 + threadIdx.x;
+        int f = 0;
+        if (i < n) {
+            const double p0 = val3[3 * i] / mx, p1 = val3[3 * i + 1] / mx, p2 = val3[3 * i + 2] / mx;
+            f = (((p1 - p0) * (p2 - p1) <= 0.0) && (p1 > thresh)) ? 1 : 0;
+        }
+        int x = f;
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; tot += wsum[w]; }
+        if (f) cand[carry + woff + (x - 1)] = idx[i];
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+}
+
+extern "C" int64_t gf3_sync_chunk_workspace_bytes(const gf3_ctx* c, int64_t n) { return gf3_sync_stream_workspace_bytes(c, n); }
+
+extern "C" int gf3_sync_chunk(const gf3_ctx* c, const void* d_buf, int64_t n, int64_t lag_lo, int64_t lag_hi, int64_t lag_offset,
+                              double* d_run_max, int64_t* d_idx, double* d_val3, int64_t cap, int64_t* n_listed,
+                              void* d_work, void* stream) {
+    DeviceGuard dg(c);
+    if (!c || !d_buf || !d_run_max || !d_idx || !d_val3 || !n_listed || !d_work || n < 3 || cap < 0)
+        return fail(c, GF3_EINVAL, "gf3_sync_chunk: bad argument");
+    const StreamWs w = stream_ws(c, n);
+    if (lag_lo < 1 || lag_hi > w.plen - 1 || lag_lo > lag_hi)
+        return fail(c, GF3_EINVAL, "gf3_sync_chunk: lags [%lld, %lld) outside [1, %lld)", (long long)lag_lo, (long long)lag_hi, (long long)(w.plen - 1));
+    *n_listed = 0;
+    if (lag_lo == lag_hi) return GF3_OK;
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)d_work;
+    double* P = (double*)(base + w.o_P);
+    double* part = (double*)(base + w.o_part);
+    int64_t* cnt = (int64_t*)(base + w.o_cnt);
+    int64_t* offs = (int64_t*)(base + w.o_off);
+    int64_t* total = (int64_t*)(base + w.o_misc + 8);
+    const CorrPlan& pl = c->stream_plan;
+    {   // P of the whole buffer, all fp64 (the overlap-save of gf3_sync_stream's fp64 path)
+        OlsArgs a{};
+        a.t = pl.t; a.in = d_buf; a.n_in = n; a.dt = c->cfg.in_dtype;
+        a.Hq = pl.d_Hq; a.Q = pl.Q; a.H = pl.Lp; a.Lc = c->Lc;
+        a.spec = (cplx*)(base + w.o_spec); a.nwin = w.nwin; a.plen = w.plen; a.corr = P; a.part = part;
+        const size_t lds = fft_lds_bytes(pl.NC);
+        hipError_t e = hipSuccess;
+        auto pad8 = [](int64_t x) { return (x + 7) / 8 * 8; };
+        a.nitems = w.nwin;
+        DISPATCH_NC(pl.NC, a.dt, e = launch((spec_kernel<NCC, DTC>), pad8(w.nwin), NCC / 8, lds, st, a));
+        HIPCHK(c, e);
+        a.nitems = (w.nblk + OLS_B - 1) / OLS_B;
+        switch (pl.NC) {
+#ifndef GF3_DEV_BUILD
+            case 512:  e = launch(ols_kernel<512>, pad8(a.nitems), 64, lds, st, a); break;
+            case 1024: e = launch(ols_kernel<1024>, pad8(a.nitems), 128, lds, st, a); break;
+            case 4096: e = launch(ols_kernel<4096>, pad8(a.nitems), 512, lds, st, a); break;
+#endif
+            default:   e = launch(ols_kernel<2048>, pad8(a.nitems), 256, lds, st, a); break;
+        }
+        HIPCHK(c, e);
+    }
+    // the maximum of the lags this piece owns joins the running maximum (the ols workgroups' own maxima cover lags at
+    // the buffer's edges whose sums are cut off: they are not values of the stream's P)
+    int64_t gmax = (lag_hi - lag_lo + CK_THREADS * 8 - 1) / (CK_THREADS * 8);
+    gmax = gmax < 1 ? 1 : (gmax > w.nb_max ? w.nb_max : (gmax > 2048 ? 2048 : gmax));
+    hipLaunchKernelGGL(ck_max_kernel, dim3((unsigned)gmax), dim3(CK_THREADS), 0, st, (const double*)P, lag_lo, lag_hi, part);
+    hipLaunchKernelGGL(ck_fold_max, dim3(1), dim3(256), 0, st, (const double*)part, (int)gmax, d_run_max);
+    const int64_t nb = (lag_hi - lag_lo + PK_THREADS * PK_ITEMS - 1) / (PK_THREADS * PK_ITEMS);     // <= nb_c of the workspace
+    hipLaunchKernelGGL(ck_list_kernel, dim3((unsigned)nb), dim3(PK_THREADS), 0, st, (const double*)P, lag_lo, lag_hi, (const double*)d_run_max,
+                       c->cfg.thresh, lag_offset, cnt, (const int64_t*)nullptr, (int64_t*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, nb, offs, total, (const long long*)nullptr, (const long long*)nullptr);
+    HIPCHK(c, hipGetLastError());
+    int64_t want = 0;
+    HIPCHK(c, hipMemcpyAsync(&want, total, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *n_listed = want;
+    if (want > cap) return fail(c, GF3_ERANGE, "gf3_sync_chunk: %lld lags to keep exceed capacity %lld", (long long)want, (long long)cap);
+    if (want > 0) {
+        hipLaunchKernelGGL(ck_list_kernel, dim3((unsigned)nb), dim3(PK_THREADS), 0, st, (const double*)P, lag_lo, lag_hi, (const double*)d_run_max,
+                           c->cfg.thresh, lag_offset, cnt, (const int64_t*)offs, d_idx, d_val3);
+        HIPCHK(c, hipGetLastError());
+    }
+    return GF3_OK;
+}
+
+extern "C" int64_t gf3_sync_decide_workspace_bytes(const gf3_ctx* c, int64_t n_listed) {
+    if (!c || n_listed < 0) return 0;
+    return (int64_t)((size_t)(n_listed + 2) * 8 + 64);
+}
+
+extern "C" int gf3_sync_decide(const gf3_ctx* c, const int64_t* d_idx, const double* d_val3, int64_t n_listed, const double* d_max,
+                               int64_t nz_total, int64_t* d_peaks, int64_t cap, int64_t* n_peaks, void* d_work, void* stream) {
+    DeviceGuard dg(c);
+    if (!c || !d_max || !d_peaks || !n_peaks || !d_work || n_listed < 0 || cap < 1 || (n_listed > 0 && (!d_idx || !d_val3)))
+        return fail(c, GF3_EINVAL, "gf3_sync_decide: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int64_t* cand = (int64_t*)d_work;
+    int64_t* total = cand + n_listed + 1;
+    int64_t* np = total + 1;                               // [count, status]  (64 bytes of slack behind the list)
+    hipLaunchKernelGGL(ck_decide_kernel, dim3(1), dim3(1024), 0, st, d_idx, d_val3, n_listed, d_max, c->cfg.thresh, cand, total);
+    hipLaunchKernelGGL(pk_nms, dim3(1), dim3(NMS_THREADS), 0, st, (const int64_t*)cand, (const int64_t*)total,
+                       (int64_t)c->Lc, nz_total, d_peaks, cap, np);
+    HIPCHK(c, hipGetLastError());
+    int64_t h[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, np, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *n_peaks = h[0];
+    if (h[1] == 2) return fail(c, GF3_ERANGE, "gf3_sync_decide: %lld peaks exceed capacity %lld", (long long)h[0], (long long)cap);
+    return GF3_OK;
 }
 
 static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, uint8_t* idx, float* llr, double nv, void* stream);

@@ -367,6 +367,196 @@ class Engine:
         self._check(self.lib.gf3_soft_demap(self._h, _ptr(sym), sym.numel(), float(noise_var), _ptr(llr), self._stream()))
         return llr
 
+    # ------------------------------------------------------------------ host ingest (streams from host memory / longer than HBM)
+    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None):
+        """chirp sync + demodulation (the arithmetic of receiver.receive, OFDM.py:581-603) of a stream that lives in
+        HOST memory, piece by piece: pinned, double-buffered H2D copies on a copy stream run under the kernels of the
+        previous piece, and the result is that of the one-shot path -- the reference's rule with the GLOBAL maximum
+        (OFDM.py:359), the suppression walk, the except-branch, the dropped last detection -- for any stream length.
+
+        How the global rule survives the cut (gf3_sync_chunk / gf3_sync_decide, include/gf3rx.h): every piece folds its
+        lags into a running maximum and keeps the few lags that could still pass 0.4 x the FINAL maximum (which can
+        only be larger), with their raw fp64 values.  After each piece the rule is applied provisionally with the
+        maximum so far and the packets whose samples are resident are demodulated; at the end it is applied once more
+        with the final maximum, and only where that changes the detections (a later piece raised the maximum enough to
+        kill an earlier candidate, or un-suppressed one) are packets looked at again -- their samples re-read from the
+        host array.  Pieces overlap by Lc + one packet, so no chirp and no packet is cut.
+
+        samples: 1-D numpy array or CPU torch tensor (a pinned tensor is copied from directly; anything else is staged
+        through pinned buffers, which costs a host memcpy per piece).  chunk_samples: new samples per piece (raised to
+        two packets if smaller).  Returns dict(peaks int64 [n_det] (device), bits uint8 [n_det - 1, bytes_per_frame]
+        (device, packed), info).  Raises ValueError where the reference fails (fewer than two detections; a packet that
+        runs past the end of the stream)."""
+        import time
+        cfg = self.cfg
+        if isinstance(samples, torch.Tensor):
+            if samples.is_cuda:
+                raise ValueError("receive_host takes host memory; use sync_stream / demod_frames for device tensors")
+            x = samples.reshape(-1)
+            if x.dtype != cfg.in_dtype:
+                x = x.to(cfg.in_dtype)
+        else:
+            a = np.asarray(samples).reshape(-1)
+            want = torch.empty(0, dtype=cfg.in_dtype).numpy().dtype
+            x = torch.from_numpy(np.ascontiguousarray(a if a.dtype == want else a.astype(want)))
+        n = x.numel()
+        if n < 3:
+            raise ValueError("stream too short")
+        pinned_in = x.is_pinned()
+        Lc, L = cfg.chirp_length, cfg.M * cfg.S
+        carry = Lc + L + 8                                        # samples of the previous piece kept in front of a piece
+        H = max(int(chunk_samples), 2 * carry)
+        nchunks = -(-n // H)
+        plen = n + Lc - 1
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        copier = torch.cuda.Stream(dev)
+        bufs = [self._new((carry + min(H, n),), cfg.in_dtype) for _ in range(min(2, nchunks))]
+        stage = None if pinned_in else [torch.empty((min(H, n),), dtype=cfg.in_dtype).pin_memory() for _ in range(min(2, nchunks))]
+        ev_copied = [torch.cuda.Event() for _ in bufs]
+        run_max = torch.full((1,), float("-inf"), dtype=torch.float64, device=dev)
+        cap_list = int(list_cap or max(4096, 64 * (n // Lc + 2)))
+        idx_all = self._new((cap_list,), torch.int64)
+        val_all = self._new((cap_list, 3), torch.float64)
+        work = self._new((int(self.lib.gf3_sync_chunk_workspace_bytes(self._h, carry + min(H, n))),), torch.uint8)
+        cap_peaks = n // Lc + 8
+        peaks_dev = self._new((cap_peaks,), torch.int64)
+        dwork = self._new((int(self.lib.gf3_sync_decide_workspace_bytes(self._h, cap_list)),), torch.uint8)
+        rows = self._new((cap_peaks, self.bytes_per_frame), torch.uint8)
+        row_of, next_row = {}, 0                                  # zeros-index of a detection -> row of `rows` holding its packet's bits
+        segs, overflow = [], []                                   # per piece: (first entry, entries) of the kept list; pieces whose list did not fit
+        n_listed = 0
+        BIG = (1 << 62)
+        info = dict(chunks=nchunks, chunk_samples=H, overlap_samples=carry, pinned_input=bool(pinned_in), h2d_bytes=0,
+                    second_look_chunks=0, second_look_packets=0, provisional_detections_dropped=0)
+        t_start = time.perf_counter()
+
+        def geometry(c):
+            lo_s, hi_s = c * H, min(n, (c + 1) * H)
+            ce = min(carry, lo_s)
+            base = lo_s - ce
+            g_lo = 1 if c == 0 else lo_s - 1
+            g_hi = plen - 1 if c == nchunks - 1 else hi_s - 1
+            return lo_s, hi_s, ce, base, g_lo, g_hi
+
+        def issue_copy(c):
+            """host -> dev of piece c's new samples on the copy stream (after `ev_order` of the main stream)"""
+            b = c % 2
+            lo_s, hi_s = c * H, min(n, (c + 1) * H)
+            src = x[lo_s:hi_s]
+            if stage is not None:
+                ev_copied[b].synchronize()                        # the copy that last read this staging buffer is done
+                stage[b][: hi_s - lo_s].copy_(src)
+                src = stage[b][: hi_s - lo_s]
+            with torch.cuda.stream(copier):
+                bufs[b][carry: carry + (hi_s - lo_s)].copy_(src, non_blocking=True)
+                ev_copied[b].record(copier)
+            info["h2d_bytes"] += (hi_s - lo_s) * x.element_size()
+
+        def sync_piece(buf, n_buf, lag_lo, lag_hi, base, idx_t, val_t, cap):
+            cnt = C.c_int64(0)
+            rc = self.lib.gf3_sync_chunk(self._h, _ptr(buf), n_buf, lag_lo, lag_hi, base, _ptr(run_max), _ptr(idx_t), _ptr(val_t),
+                                         cap, C.byref(cnt), _ptr(work), self._stream())
+            if rc == _lib.GF3_ERANGE:
+                return -int(cnt.value) - 1
+            self._check(rc)
+            return int(cnt.value)
+
+        def decide(idx_t, val_t, k, nz):
+            cnt = C.c_int64(0)
+            self._check(self.lib.gf3_sync_decide(self._h, _ptr(idx_t), _ptr(val_t), k, _ptr(run_max), nz, _ptr(peaks_dev), cap_peaks,
+                                                 C.byref(cnt), _ptr(dwork), self._stream()))
+            return peaks_dev[: cnt.value].cpu().numpy()
+
+        issue_copy(0)
+        for c in range(nchunks):
+            b = c % 2
+            lo_s, hi_s, ce, base, g_lo, g_hi = geometry(c)
+            main.wait_event(ev_copied[b])
+            if ce:
+                # (the previous piece was a full one: its last `ce` new samples sit at the end of its buffer)
+                bufs[b][carry - ce: carry].copy_(bufs[1 - b][carry + H - ce: carry + H])
+            if c + 1 < nchunks:
+                ev_order = torch.cuda.Event()
+                ev_order.record(main)                              # the other buffer is free once this point is reached
+                copier.wait_event(ev_order)
+                issue_copy(c + 1)                                  # runs under this piece's kernels
+            buf = bufs[b][carry - ce: carry + (hi_s - lo_s)]
+            got = sync_piece(buf, buf.numel(), g_lo - base, g_hi - base, base, idx_all[n_listed:], val_all[n_listed:], cap_list - n_listed)
+            if got < 0:
+                overflow.append(c)                                 # (no positive maximum yet, or a threshold too low to be selective here)
+                segs.append((n_listed, 0))
+                continue
+            segs.append((n_listed, got))
+            n_listed += got
+            if overflow:
+                continue                                           # provisional decisions would miss that piece's candidates: left to the end
+            pk = decide(idx_all, val_all, n_listed, BIG)
+            ready = [int(i) for i in pk if int(i) not in row_of and int(i) + 2 >= base and int(i) + 2 + L <= hi_s]
+            if ready:
+                st = torch.tensor([i + 2 - base for i in ready], dtype=torch.int64, device=dev)
+                self.demod_frames(buf, st, out_bits=rows[next_row: next_row + len(ready)])
+                for k, i in enumerate(ready):
+                    row_of[i] = next_row + k
+                next_row += len(ready)
+
+        # ---- the end of the stream: the maximum is final
+        def piece_on_device(c):
+            lo_s, hi_s, ce, base, g_lo, g_hi = geometry(c)
+            buf = bufs[0][: ce + hi_s - lo_s]
+            buf.copy_(x[base:hi_s])                                # (second look: a plain synchronous copy)
+            info["h2d_bytes"] += buf.numel() * x.element_size()
+            return buf, base, g_lo, g_hi
+
+        extra = {}
+        for c in overflow:
+            buf, base, g_lo, g_hi = piece_on_device(c)
+            k = g_hi - g_lo
+            it, vt = self._new((k,), torch.int64), self._new((k, 3), torch.float64)
+            got = sync_piece(buf, buf.numel(), g_lo - base, g_hi - base, base, it, vt, k)
+            extra[c] = (it[:got], vt[:got])
+            info["second_look_chunks"] += 1
+        if overflow:
+            parts_i, parts_v = [], []
+            for c, (s0, k) in enumerate(segs):
+                if c in extra:
+                    parts_i.append(extra[c][0]); parts_v.append(extra[c][1])
+                elif k:
+                    parts_i.append(idx_all[s0: s0 + k]); parts_v.append(val_all[s0: s0 + k])
+            fi = torch.cat(parts_i) if parts_i else idx_all[:0]
+            fv = torch.cat(parts_v).contiguous() if parts_v else val_all[:0]
+            if fi.numel() > cap_list:
+                dwork = self._new((int(self.lib.gf3_sync_decide_workspace_bytes(self._h, fi.numel())),), torch.uint8)
+        else:
+            fi, fv = idx_all[:n_listed], val_all[:n_listed]
+        peaks = decide(fi.contiguous(), fv, fi.numel(), plen - 2)
+        if len(peaks) < 2:
+            raise ValueError("need at least one array to concatenate")      # np.vstack([]) in get_symbols (OFDM.py:400)
+        det = [int(i) for i in peaks[:-1]]                            # the last detection is always dropped (OFDM.py:395)
+        missing = [i for i in det if i not in row_of]
+        for i in missing:
+            if i + 2 + L > n:
+                raise ValueError("packet runs past the end of the stream")
+        info["provisional_detections_dropped"] = len(set(row_of) - set(det))
+        for k0 in range(0, len(missing), 64):                         # second look at single packets: samples re-read from the host
+            grp = missing[k0: k0 + 64]
+            seg = torch.stack([x[i + 2: i + 2 + L] for i in grp]).to(dev)
+            info["h2d_bytes"] += seg.numel() * x.element_size()
+            if next_row + len(grp) > rows.shape[0]:
+                rows = torch.cat([rows, self._new((len(grp), self.bytes_per_frame), torch.uint8)])
+            self.demod_frames(seg.reshape(-1), torch.arange(len(grp), device=dev, dtype=torch.int64) * L,
+                              out_bits=rows[next_row: next_row + len(grp)])
+            for k, i in enumerate(grp):
+                row_of[i] = next_row + k
+            next_row += len(grp)
+            info["second_look_packets"] += len(grp)
+        order = torch.tensor([row_of[i] for i in det], dtype=torch.int64, device=dev)
+        bits = rows[order]
+        torch.cuda.synchronize(dev)
+        info["seconds"] = time.perf_counter() - t_start
+        info["max"] = float(run_max.item())
+        return dict(peaks=torch.from_numpy(peaks).to(dev), bits=bits, info=info)
+
     # ------------------------------------------------------------------ bit helpers (layout only)
     def unpack_bits(self, packed):
         """[F, bytes_per_frame] uint8 -> [F * D*C*mu] uint8 0/1 (np.unpackbits order), on device."""

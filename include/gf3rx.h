@@ -81,6 +81,8 @@ typedef struct {
 typedef struct gf3_ctx gf3_ctx;
 
 const char *gf3_version(void);
+/* SHA-256 (hex) of the sources + compiler flags this binary was built from, "unknown" for a build made by hand */
+const char *gf3_source_hash(void);
 
 /* replaces CamG.__init__ + sync_chirp (OFDM.py:18-109): builds twiddles, the
  * chirp replica and its partition spectra, demap tables, on the current device */
@@ -193,6 +195,44 @@ int gf3_sync_stream_ex(const gf3_ctx *ctx, const void *d_r, int64_t n,
  * int), and the h_info4 of the CALLING THREAD's last gf3_sync_stream / gf3_sync_stream_ex */
 int gf3_sync_stream_mode(gf3_ctx *ctx, int32_t mode);
 int gf3_sync_stream_info(const gf3_ctx *ctx, int64_t *h_out4);
+/*
+ * chirp_method (OFDM.py:356-372) on a stream that arrives piece by piece -- host ingest through pinned buffers, streams
+ * longer than HBM -- with the reference's EXACT global rule.  The 0.4 threshold is relative to the maximum of the whole
+ * stream (OFDM.py:359), known only at the end; so each piece keeps the running maximum and the few lags that could
+ * still pass whatever the final maximum is, with the raw fp64 values the rule looks at, and the rule itself is applied
+ * afterwards (or provisionally, with the maximum so far) by gf3_sync_decide.  Engine.receive_host (engine.py) drives
+ * the two calls; INTEGRATION.md shows the loop.
+ *
+ * gf3_sync_chunk: all-fp64 matched filter of d_buf[0..n) -- a piece of the stream with at least Lc + 1 samples of the
+ * previous piece in front of it (none at the stream's start) -- restricted to the lags [lag_lo, lag_hi) of the buffer's
+ * own full convolution P_buf[m] = sum_k buf[m-Lc+1+k] chirp[k] (1 <= lag_lo <= lag_hi <= n+Lc-2; the caller chooses
+ * them so that every lag of the stream is owned by exactly one piece and its taps and both neighbours are complete).
+ *   *d_run_max (device): in  = maximum of the earlier pieces (-inf before the first), NumPy's NaN rule;
+ *                        out = maximum including this piece's lags
+ *   listed: every owned lag g with P[g] >= thresh * run_max * (1 - 1e-6) (every owned lag while run_max is not a
+ *           positive finite number): d_idx[k] = g - 1 + lag_offset (the zeros-index of OFDM.py:360 in the caller's
+ *           global numbering), d_val3[3k..3k+2] = P[g-1], P[g], P[g+1]; ascending; *n_listed (host) = how many.
+ *   GF3_ERANGE with *n_listed = the number wanted when cap is too small (nothing is written): look at the piece again
+ *   with a larger list, or once the final maximum is known (preset *d_run_max).
+ *   d_work: gf3_sync_chunk_workspace_bytes(ctx, n) bytes.  Synchronises the stream (it returns a count).
+ */
+int64_t gf3_sync_chunk_workspace_bytes(const gf3_ctx *ctx, int64_t n);
+int gf3_sync_chunk(const gf3_ctx *ctx, const void *d_buf, int64_t n,
+                   int64_t lag_lo, int64_t lag_hi, int64_t lag_offset,
+                   double *d_run_max, int64_t *d_idx, double *d_val3, int64_t cap,
+                   int64_t *n_listed, void *d_work, void *stream);
+/*
+ * gf3_sync_decide: the reference's rule on the listed raw values -- p = P / *d_max first, candidate <=>
+ * (p1-p0)(p2-p1) <= 0 and p1 > thresh (OFDM.py:359-361) -- then the suppression walk over Lc samples with the
+ * except-branch (OFDM.py:364-370) for a stream whose zeros array has nz_total = n_total + Lc - 3 entries (pass
+ * INT64_MAX / 2 for a provisional decision on a stream that has not ended).  Peaks as gf3_sync_stream returns them.
+ *   d_work: gf3_sync_decide_workspace_bytes(ctx, n_listed) bytes.  Synchronises the stream.
+ */
+int64_t gf3_sync_decide_workspace_bytes(const gf3_ctx *ctx, int64_t n_listed);
+int gf3_sync_decide(const gf3_ctx *ctx, const int64_t *d_idx, const double *d_val3, int64_t n_listed,
+                    const double *d_max, int64_t nz_total,
+                    int64_t *d_peaks, int64_t cap, int64_t *n_peaks, void *d_work, void *stream);
+
 /* tests: the fp32 screening pass alone.  d_p32 [n+Lc-1] float; d_blk [2*nblk] float: per block of *h_hop lags its
  * maximum, then the bound on |P32 - P| of its lags (nblk = ceil((n+Lc-1) / hop)) */
 int gf3_debug_stream_screen(gf3_ctx *ctx, const void *d_r, int64_t n, float *d_p32, float *d_blk,

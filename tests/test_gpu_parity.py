@@ -1066,3 +1066,110 @@ def test_two_threads_two_streams_share_one_context():
     for i in range(2):
         assert np.array_equal(got[i][0], alone[i][0]) and np.array_equal(got[i][1], alone[i][1]) and got[i][2] == alone[i][2]
     assert "exceed capacity" in texts[0] and "exceed capacity" not in texts[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# host ingest: Engine.receive_host (gf3_sync_chunk + gf3_sync_decide) -- the stream cut into pieces, the reference's
+# global rule intact
+# ---------------------------------------------------------------------------------------------------------------
+def _config1_case():
+    g = load("g1b_config1_64f")
+    pts, bt = orc.qpsk_table()
+    p = orc.RxParams(N=int(g["N"]), CP=int(g["CP"]), P=int(g["P"]), D=int(g["D"]), lo=int(g["lo"]),
+                     hi=int(g["hi"]), const_points=pts, const_bits=bt, known_bits=g["known_bits"])
+    F = int(g["F"])
+    payload = np.random.RandomState(20261003).randint(0, 2, F * p.D * p.C * p.mu)
+    r = orc.tx_stream(payload, g["fill"], p, gaps=g["gaps"], lead=int(g["lead"]), tail=int(g["tail"]))
+    return g, p, F, r
+
+
+@pytest.mark.parametrize("storage", ["f64_pageable", "f32_pinned"])
+def test_receive_host_chunked_equals_one_shot_and_reference(storage):
+    """BASELINE config 1 (64 frames, the reference's own bits in the g1b fixture) from HOST memory in 33 pieces of
+    two packets each: peaks and bits of the one-shot device path and of the reference."""
+    g, p, F, r = _config1_case()
+    dt = torch.float64 if storage.startswith("f64") else torch.float32
+    eng = engine_for(p, in_dtype=dt)
+    if storage == "f32_pinned":
+        host = torch.from_numpy(r.astype(np.float32)).pin_memory()
+        ref_bits = orc.receive(r.astype(np.float32).astype(np.float64), p)["bits"]
+    else:
+        host, ref_bits = r, unpack(g)
+    out = eng.receive_host(host, chunk_samples=1)                      # (raised to two packets per piece)
+    info = out["info"]
+    assert info["chunks"] >= 4 and info["pinned_input"] == (storage == "f32_pinned"), info
+    x = torch.as_tensor(host).cuda()
+    one = eng.sync_stream(x)
+    assert torch.equal(out["peaks"], one) and out["peaks"].numel() == F + 1
+    bits_one = eng.demod_frames(x, (one + 2)[:-1])["bits"]
+    assert torch.equal(out["bits"], bits_one)
+    assert np.array_equal(eng.unpack_bits(out["bits"]).cpu().numpy(), ref_bits)
+    assert info["second_look_chunks"] == 0 and info["second_look_packets"] == 0, info     # a clean stream needs no second look
+    assert info["h2d_bytes"] == len(r) * x.element_size()                                 # every sample crossed PCIe once
+    # ... and as ONE piece it is the one-shot path
+    out1 = eng.receive_host(host, chunk_samples=1 << 24)
+    assert out1["info"]["chunks"] == 1 and torch.equal(out1["peaks"], one) and torch.equal(out1["bits"], bits_one)
+
+
+def _crafted_stream(p, lead_zeros):
+    """[lead | weak bare chirp W1 (0.3) overlapping the chirp of packet 0 sent at HALF amplitude | 21 000 zeros |
+    packets 1..5 at full amplitude | terminating chirp | tail].  While only the first piece has been seen the maximum
+    is packet 0's (0.5): W1 (0.3 / 0.5 = 0.6 > 0.4) is a candidate, comes first and suppresses packet 0's chirp, which
+    lies within Lc of it.  A later piece raises the maximum to 1.0: W1 (0.3) dies and packet 0's chirp (0.5) stands."""
+    rs = np.random.RandomState(77)
+    F = 6
+    payload = rs.randint(0, 2, F * p.D * p.C * p.mu)
+    fill = (np.array([1 + 1j]) / np.sqrt(2))[: p.K - p.C] if p.K > p.C else np.zeros(0, complex)
+    rows = orc.tx_frames(payload, fill, p)                               # [F, Lc + M S]
+    chirp = orc.chirp_replica(p)
+    Lc = p.Lc
+    s = np.concatenate([np.zeros(lead_zeros + Lc // 2), 0.5 * rows[0], np.zeros(21000), rows[1:].reshape(-1), chirp, np.zeros(40)])
+    s[lead_zeros: lead_zeros + Lc] += 0.3 * chirp / 0.2 * 0.2            # W1 starts Lc/2 before packet 0's chirp
+    s[lead_zeros:] += 1e-5 * rs.randn(len(s) - lead_zeros)              # (the lead-in stays EXACTLY zero: no positive maximum there)
+    return s, payload
+
+
+@pytest.mark.parametrize("lead_zeros,list_cap", [(50, None), (50, 4), (45000, None)])
+def test_receive_host_later_piece_changes_earlier_decisions(lead_zeros, list_cap):
+    """The hard case of the global-max rule (OFDM.py:359): a later piece raises the maximum, which kills a candidate
+    the first piece had accepted AND thereby un-suppresses another one -- a detection the provisional pass never
+    demodulated (second look at that packet).  With 45 000 leading zeros the first piece has no positive maximum at
+    all, so every one of its lags stays listed, the list overflows and the piece itself is looked at again; a small
+    list capacity forces the same path on the ordinary stream.  Expected: exactly the oracle's detections and bits."""
+    g = load("g1_n1024_qpsk")
+    p = params_of(g)
+    r, payload = _crafted_stream(p, lead_zeros)
+    ref = orc.receive(r, p)
+    want_peaks = np.flatnonzero(ref["zeros"])
+    assert len(want_peaks) == 7                                         # packets 0..5 + the terminating chirp: W1 is NOT among them
+    eng = engine_for(p)
+    out = eng.receive_host(r, chunk_samples=1, list_cap=list_cap)
+    info = out["info"]
+    assert info["chunks"] >= 4, info
+    assert np.array_equal(out["peaks"].cpu().numpy(), want_peaks), (out["peaks"], want_peaks, info)
+    assert np.array_equal(eng.unpack_bits(out["bits"]).cpu().numpy(), ref["bits"])
+    assert np.array_equal(ref["bits"], payload)
+    x = torch.from_numpy(r).cuda()
+    assert torch.equal(eng.sync_stream(x), out["peaks"])                # the one-shot device path agrees
+    if lead_zeros == 50 and list_cap is None:
+        # the provisional pass accepted W1, demodulated what followed it, and had to drop that at the end;
+        # packet 0 was only found with the final maximum
+        assert info["provisional_detections_dropped"] >= 1 and info["second_look_packets"] >= 1, info
+    else:
+        assert info["second_look_chunks"] >= 1, info
+
+
+def test_receive_host_fails_where_the_reference_fails():
+    g = load("g1_n1024_qpsk")
+    p = params_of(g)
+    eng = engine_for(p)
+    rs = np.random.RandomState(5)
+    with pytest.raises(ValueError):                                     # no chirp at all: np.vstack([]) in the reference
+        eng.receive_host(1e-3 * rs.randn(150000), chunk_samples=1)
+    r = g["r"]
+    cut = r[: int(g["peaks"][0]) + 2 + 3 * p.S]                         # first packet cut short, then a chirp glued on
+    bad = np.concatenate([cut, orc.chirp_replica(p), np.zeros(10)])
+    with pytest.raises(ValueError):
+        orc.receive(bad, p)
+    with pytest.raises(ValueError):
+        eng.receive_host(bad, chunk_samples=1)
