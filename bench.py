@@ -352,7 +352,7 @@ def demod_16qam_roofline(dev, args, reps=20):
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4      # 1 024 SIMDs, one wave64 VALU instruction per 4 cycles, 2.4 GHz
 
 
-def stream_sync_roofline(dev, frames=4096, pmc=None):
+def stream_sync_roofline(dev, frames=4096, pmc=None, h2d=True):
     """BASELINE config 3 (tools/config3.py): 4 096 16-QAM packets as ONE stream through the measured 30-tap channel,
     stream-mode chirp sync with the reference's global-max / first-extremum / suppression rule, then demod; median of
     20 passes after 3 warm-ups.  The call is NOT memory-bound: the fp32 screen transforms every sample
@@ -383,8 +383,43 @@ def stream_sync_roofline(dev, frames=4096, pmc=None):
                                     "samples_per_s_sync_plus_demod": res["samples_per_s"], "ber_vs_payload": res["ber"],
                                     "sync_offsets_exact": res["sync_offsets_as_expected_plus1"],
                                     "sync_path": res["sync_path"]}}
+    if h2d:
+        out.update(host_ingest_leg(eng, r, starts))
     eng.close()
     return out
+
+
+def host_ingest_leg(eng, r, starts_one_shot, chunk_samples=1 << 25, reps=3):
+    """SURVEY 8(d) "H2D upload excluded and reported separately": the same config-3 stream from PINNED HOST memory
+    through Engine.receive_host -- 32 Mi-sample pieces, double-buffered H2D on a copy stream under the previous piece's
+    kernels, the reference's global-max rule kept exact across the pieces (gf3_sync_chunk / gf3_sync_decide).  Never
+    `value`: the headline is quoted with the samples resident in HBM."""
+    host = torch.empty(r.numel(), dtype=r.dtype).pin_memory()
+    host.copy_(r)
+    torch.cuda.synchronize()
+    dst = torch.empty_like(r)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(host, non_blocking=True); torch.cuda.synchronize()
+    e0.record(); dst.copy_(host, non_blocking=True); e1.record(); torch.cuda.synchronize()
+    copy_only = host.numel() * host.element_size() / (e0.elapsed_time(e1) * 1e-3)
+    del dst
+    ts, res = [], None
+    for _ in range(1 + reps):                                   # one warm-up (pinned staging, workspaces)
+        t = time.perf_counter(); res = eng.receive_host(host, chunk_samples=chunk_samples); ts.append(time.perf_counter() - t)
+    t = float(np.median(ts[1:]))
+    one = eng.demod_frames(r, starts_one_shot)["bits"]
+    info = res["info"]
+    return {"h2d": {"path": "Engine.receive_host: pinned host array -> two device buffers, H2D on a copy stream under the previous piece's "
+                            "kernels; all-fp64 chunked sync with the exact global-max rule + demod per piece",
+                    "workload": "BASELINE config 3 stream (321 M f32 samples, 4 096 16-QAM packets) from pinned host memory",
+                    "samples": int(r.numel()), "chunks": info["chunks"], "chunk_samples": info["chunk_samples"],
+                    "seconds": t, "timing": f"median of {reps} passes after 1 warm-up (host wall clock, synchronised)",
+                    "samples_per_s_with_upload": r.numel() / t, "h2d_GB_per_s_achieved": info["h2d_bytes"] / t / 1e9,
+                    "h2d_copy_only_GB_per_s": copy_only / 1e9,
+                    "peaks_equal_one_shot": bool(torch.equal((res["peaks"] + 2)[:-1], starts_one_shot)),
+                    "bits_equal_one_shot": bool(torch.equal(res["bits"], one)),
+                    "second_look_chunks": info["second_look_chunks"], "second_look_packets": info["second_look_packets"],
+                    "note": "reported separately, never `value` (SURVEY 8d)"}}
 
 
 def rccl_version():
@@ -622,7 +657,7 @@ def main():
             extra.update(demod_16qam_roofline(dev, args))
             extra.update(config5_rooflines(dev))
         if not args.no_stream:
-            extra.update(stream_sync_roofline(dev, pmc=pmc))
+            extra.update(stream_sync_roofline(dev, pmc=pmc, h2d=not args.no_h2d))
 
     if rank == 0:
         from gf3_audio_modem_amd import _lib

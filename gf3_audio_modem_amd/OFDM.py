@@ -350,6 +350,13 @@ class receiver(transmitter):
         print(self)
         r = _as_samples(signal)
         eng = self._engine(r.dtype)
+        # Long recordings (or when `host_chunk_samples` is set on the receiver) are taken from host memory piece by piece
+        # -- Engine.receive_host: pinned double-buffered upload under the kernels, the global-max rule of OFDM.py:359
+        # kept exact across the pieces -- instead of being uploaded whole; the plots need every packet's symbols and
+        # stay on the one-shot path.
+        chunk = getattr(self, "host_chunk_samples", None)
+        if not graph_output and (chunk or len(r) > (1 << 27)):
+            return self._receive_chunked(eng, r, int(chunk or (1 << 25)))
         x = eng._samples(r)
         peaks = eng.sync_stream(x)
         starts = (peaks + 2)[:-1]                               # OFDM.py:393-395
@@ -370,6 +377,25 @@ class receiver(transmitter):
         if graph_output:
             self._plots(o["Hest"].cpu().numpy(), Hest_start, Hest_end, o["eq"].cpu().numpy())
         return bits, Hest_start[0], Hest_end[0]
+
+    def _receive_chunked(self, eng, r, chunk):
+        try:
+            res = eng.receive_host(r, chunk_samples=chunk)
+        except ValueError as e:                                 # the reference's own failures, with its messages
+            if "runs past the end" in str(e):
+                raise ValueError("all the input array dimensions except for the concatenation axis must match exactly")
+            raise
+        starts = (res["peaks"] + 2)[:-1]
+        self.no_packets = int(starts.numel())
+        print("Number of received OFDM symbols:    " + str(self.no_packets * self.packet_length))
+        bits = self.decode(eng.unpack_bits(res["bits"]).to(torch.int64).cpu().numpy())
+        print("Number of received bits:            " + str(len(bits)))
+        L = (2 * self.no_pilots + self.packet_length) * (self.cp_length + self.ofdm_symbol_size)
+        s0 = int(starts[0])                                     # channel estimates of the first packet (the return triple)
+        o = eng.demod_frames(eng._samples(r[s0: s0 + L]), [0], want=("Hs", "He", "slope"))
+        self._last_slope = o["slope"].cpu().numpy()
+        self._last_ingest = res["info"]
+        return bits, o["Hs"].cpu().numpy()[0], o["He"].cpu().numpy()[0]
 
     # ---- plots (OFDM.py:553-577, 615-654): host-side matplotlib, optional ---------------
     def _plots(self, Hest, Hest_start, Hest_end, data_symbols):

@@ -188,16 +188,27 @@ GF3_DEV int scan_table(cplx e, const double* cre, const double* cim, int M) {
     }
     return best;
 }
-// Nearest of n equally spaced levels lo, lo + 1/inv, ...: index in units of the spacing by one rint().  `clear` is
-// false within 1e-9 of a spacing of a decision boundary (and for NaN / Inf), where the caller falls back to the
-// literal scan; everywhere else the per-axis choice IS the argmin over the grid, with a margin nine orders above the
-// rounding of either evaluation.
-GF3_DEV uint32_t uni_axis(double x, double lo, double inv, int n, unsigned long long pack, bool& clear) {
-    const double t = (x - lo) * inv;
-    const double r = fmin(fmax(rint(t), 0.0), (double)(n > 1 ? n - 1 : 0));     // (never negative: r indexes `pack`)
-    const double d = fabs(t - r);
-    clear = (d < 1e300) && !(fabs(0.5 - d) < 1e-9);
-    return (uint32_t)(pack >> (8 * (int)r)) & 0xffu;
+// Nearest of n equally spaced levels lo, lo + 1/inv, ...  The caller hands in tp = (x - lo) inv + 1/2 (one fma on the
+// un-normalised symbol: x = ep / mag, so tp = ep (inv / mag) + (1/2 - lo inv)); the level index is trunc(tp) clamped to
+// the grid (v_cvt_i32_f64 truncates; below the grid it is clamped to 0 anyway, inside it trunc = floor) and its label
+// byte is picked out of the packed table by one v_perm_b32.  `clear` is false within 1e-9 of a spacing of a decision
+// boundary -- tp within 1e-9 of an integer -- and for NaN / Inf / |tp| >= 2^52, where the caller falls back to the
+// literal scan; everywhere else the per-axis choice IS the argmin over the grid, with a margin five orders above the
+// error of tp (one Newton step on v_rcp_f64: ~1e-14 relative).  (Beyond the outermost levels tp may be flagged although
+// the edge level is certain: a spurious, harmless visit of the literal scan.)  The flag is formed by the caller from the
+// two axes' `off` in one comparison: clear <=> max(|offI|, |offQ|) < 1/2 - 1e-9 (NaN compares false).
+GF3_DEV uint32_t uni_axis(double tp, int n, unsigned long long pack, double& off) {
+    off = __builtin_amdgcn_fract(tp) - 0.5;                                // |off| -> 1/2 at a boundary (the caller tests both axes at once)
+    int r = (int)tp;
+    asm("v_med3_i32 %0, %0, 0, %1" : "+v"(r) : "v"(n > 1 ? n - 1 : 0));    // clamp to the grid (never negative: r indexes `pack`)
+    // byte r of the packed label table; the selector's upper bytes are zero and pick byte 0 into the result's upper
+    // bytes, which nobody looks at: the label is stored with a byte store
+    return __builtin_amdgcn_perm((uint32_t)(pack >> 32), (uint32_t)pack, (uint32_t)r);
+}
+// 1/x to ~1e-14 relative: v_rcp_f64 seed (2^-23) + one Newton step
+GF3_DEV double rcp_n1(double x) {
+    const double y = __builtin_amdgcn_rcp(x);
+    return fma(y, fma(-x, y, 1.0), y);
 }
 // MODE_FULL : per-symbol dumps (eq, eq_all, Hest) + literal table scan on the equalised symbol
 // MODE_SCAN : bits only, any constellation: normalise and scan literally
@@ -491,8 +502,9 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     }
     // data position of every slot, resolved once: a lookup inside the symbol loop would put a vmcnt(0) wait
     // behind the packed-word stores and the next symbol's prefetch
-    // (QPSK mode; the table modes have no registers to spare for it and recompute the position per symbol --
-    //  plain arithmetic for a contiguous band)
+    // (QPSK mode; the table modes have no registers to spare for it -- even packed two to a register the positions push
+    //  the kernel from 240 VGPRs to 256 and into spills -- and recompute the position per symbol: plain arithmetic for a
+    //  contiguous band)
     int psl[8];
     if constexpr (MODE == MODE_QPSK) {
 #pragma unroll
@@ -529,6 +541,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
             // (decide_fast).  A decision within 1e-9 of a spacing of a boundary, a NaN / Inf symbol or a table that
             // is not a uniform grid is only MARKED here; the marked carriers are re-decided below by the literal scan.
             uint32_t unclear = 0;
+            const double cI = 0.5 - a.ug.loI * a.ug.invI, cQ = 0.5 - a.ug.loQ * a.ug.invQ;      // (wave-uniform)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int n = bin_of(s) - 1;
@@ -538,8 +551,12 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
                 const int ps = pos_of(s);
                 const double2 md = mags[s * T + tid];
                 const double mag = fma(md.y, fl, md.x);
-                const cplx e = cscale(ep, rcp_nr(mag));
+                // bits only: the decision needs (ep / mag - lo) inv to far less than full precision (the margin of `clear`
+                // is 1e-9), so one Newton step serves and the quotient itself is never formed; the dumps of MODE_FULL
+                // get the fully rounded reciprocal
+                const double rm = FULL ? rcp_nr(mag) : rcp_n1(mag);
                 if constexpr (FULL) {
+                    const cplx e = cscale(ep, rm);
                     if (live_of(s)) {
                         if (a.Hest) a.Hest[((int64_t)f * D + l) * K + n] = cscale(g, mag * (1.0 / XS));
                         if (a.eq_all) a.eq_all[((int64_t)f * D + l) * K + n] = e;
@@ -548,11 +565,11 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
                 }
                 if (ps >= 0) {
                     if (a.ug.nI > 0) {                                     // (wave-uniform) a grid with equally spaced levels
-                        bool ci, cq;
-                        const uint32_t li = uni_axis(e.x, a.ug.loI, a.ug.invI, a.ug.nI, a.ug.packI, ci);
-                        const uint32_t lq = uni_axis(e.y, a.ug.loQ, a.ug.invQ, a.ug.nQ, a.ug.packQ, cq);
+                        double oi, oq;
+                        const uint32_t li = uni_axis(fma(ep.x, rm * a.ug.invI, cI), a.ug.nI, a.ug.packI, oi);
+                        const uint32_t lq = uni_axis(fma(ep.y, rm * a.ug.invQ, cQ), a.ug.nQ, a.ug.packQ, oq);
                         lab_l[ps] = (uint8_t)(li | lq);
-                        if (!(ci && cq)) unclear |= 1u << s;
+                        if (!(fmax(fabs(oi), fabs(oq)) < 0.5 - 1e-9)) unclear |= 1u << s;
                     } else unclear |= 1u << s;                             // any other table: every data carrier takes the literal scan
                 }
             }
@@ -2201,7 +2218,13 @@ static int sync_stream_screened(const gf3_ctx* c, const void* d_r, int64_t n, co
         const int64_t slots = 2 * (int64_t)c->n_cu;                         // (the LDS staging allows two workgroups per CU)
         const int64_t wgs = (w.s_cap + 3) / 4;                               // (a wave per cell at a time)
         const unsigned grid = (unsigned)(wgs < slots ? wgs : slots);
+#if GF3_REFINE_MFMA
+        const int64_t wg4 = 4 * slots;                                       // (no LDS staging: more resident waves, a wave per cell)
+        DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine_mfma_kernel<DTC>), dim3((unsigned)(wg4 < wgs ? wg4 : wgs)), dim3(SCR_REF_THREADS), 0, st, a));
+        (void)grid;
+#else
         DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine_kernel<DTC>), dim3(grid), dim3(SCR_REF_THREADS), 0, st, a));
+#endif
         HIPCHK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(scr_decide_kernel, dim3((unsigned)((w.s_cap + 255) / 256)), dim3(256), 0, st, (const int64_t*)cell, (const double*)cval, misc,

@@ -933,6 +933,97 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
     }
 }
 
+// The same re-evaluation on the fp64 matrix cores.  With taps k = 16 a + b and s = j + b, the 16 lags of a cell are the
+// anti-diagonal sums  P_j = sum_b G[j + b][b]  of  G[s][b] = sum_a x[16 a + s] c[16 a + b]  (s < 31), a 31 x 16 x (Lc / 16)
+// matrix product: twice the multiply-adds of the dot products, but v_mfma_f64_16x16x4 takes one coalesced operand per lane
+// per 1024 of them (lane l: x[64 kb + l] resp. x[64 kb + 16 + l] for the two row tiles, c[64 kb + l] for both), so there is
+// no staging through LDS, no per-lane sliding window and nothing to wait for but the loads.  One wave per cell; the sums
+// of a product are accumulated in a fixed order, so the values are reproducible.
+#ifndef GF3_REFINE_MFMA
+#define GF3_REFINE_MFMA 0
+#endif
+typedef double scr_d4 __attribute__((ext_vector_type(4)));
+template <int DT>
+__global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_mfma_kernel(RefineArgs a) {
+    __shared__ double Gs[SCR_REF_THREADS / 64][32 * 17];
+    typedef typename RawT<DT>::E E;
+    if (a.misc->status & 1) return;
+    // The cells are dealt to the waves by a fixed stride (every cell costs the same), so the loop is a counted loop over
+    // wave-uniform scalars.  The first version drew cells from the work counter inside a `while (true)` and compared the
+    // drawn number with an `ncell` the compiler kept in a vector register: to the compiler the loop exit was a per-lane
+    // decision, it built the loop out of EXEC masks, and once lane 0 had been masked off `readfirstlane` returned the
+    // `drawn` of a lane that never drew -- zero -- so the wave re-evaluated cell 0 for ever.  That is the run that did
+    // not return at the end of round 2 (and again, under a 120 s limit, in round 3 before this change).
+    auto first_lane64 = [](unsigned long long v) -> long long {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    const long long ncell = first_lane64((unsigned long long)a.misc->ncell);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* G = Gs[wave];
+    const int nkb = (a.Lc + 63) / 64;                 // blocks of 64 taps
+    const E* xin = (const E*)a.in;
+    const long long nwaves = (long long)gridDim.x * (SCR_REF_THREADS / 64);
+    for (long long cur = (long long)blockIdx.x * (SCR_REF_THREADS / 64) + wave; cur < ncell; cur += nwaves) {
+        const int64_t c = (int64_t)first_lane64((unsigned long long)a.cells[cur]);
+        const int64_t i0 = GF3_SCR_CELL * c - (a.Lc - 1);
+        scr_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const bool inside = i0 >= 0 && i0 + (int64_t)64 * nkb + 16 <= a.n_in;      // (uniform)
+        if (inside) {
+            const E* xl = xin + i0 + lane;
+#pragma unroll 4
+            for (int kb = 0; kb < nkb; ++kb) {
+                const int k = 64 * kb + lane;
+                const double xa = (double)xl[64 * kb], xb = (double)xl[64 * kb + 16];
+                const double cv = a.chirp[k < a.Lc ? k : a.Lc - 1];
+                const double cb = k < a.Lc ? cv : 0.0;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, cb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb, cb, acc1, 0, 0, 0);
+            }
+        } else {
+            const int64_t last_i = a.n_in - 1;
+            for (int kb = 0; kb < nkb; ++kb) {
+                const int k = 64 * kb + lane;
+                const int64_t ia = i0 + k, ib = ia + 16;
+                const int64_t ca = ia < 0 ? 0 : (ia > last_i ? last_i : ia), cb2 = ib < 0 ? 0 : (ib > last_i ? last_i : ib);
+                const double va = (double)xin[ca], vb = (double)xin[cb2];
+                const double xa = ia == ca ? va : 0.0, xb = ib == cb2 ? vb : 0.0;
+                const double cv = a.chirp[k < a.Lc ? k : a.Lc - 1];
+                const double cb = k < a.Lc ? cv : 0.0;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, cb, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xb, cb, acc1, 0, 0, 0);
+            }
+        }
+        // D[row][col]: lane holds rows (lane >> 4) + 4 r, r = 0..3, of column lane & 15
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (lane >> 4) + 4 * r, col = lane & 15;
+            G[row * 17 + col] = acc0[r];
+            G[(16 + row) * 17 + col] = acc1[r];
+        }
+        asm volatile("" ::: "memory");                 // (one wave: LDS serves its instructions in order)
+        double Pj = 0.0;
+        if (lane < 16) {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) Pj += G[(lane + b) * 17 + b];
+            a.cell_val[cur * 16 + lane] = Pj;
+        }
+        asm volatile("" ::: "memory");
+        const int64_t m0 = GF3_SCR_CELL * c;
+        const bool valid = lane < 16 && m0 + lane < a.plen;
+        const unsigned long long nanb = __ballot(valid && !(Pj == Pj));
+        double mx = valid ? Pj : -INFINITY;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) mx = fmax(mx, __shfl_xor(mx, d, 64));
+        if (lane == 0) {
+            if (nanb) atomicOr(&a.misc->m_nan, 1u);
+            else if (mx > -INFINITY) atomicMax(&a.misc->m_key, scr_key(mx));
+        }
+    }
+}
+
 // candidates of every listed cell: the reference's rule on the fp64 values, division by the maximum first
 // (OFDM.py:359-361).  One thread per cell; bit j of the mask: zeros-index 14 c + j is a candidate.
 __global__ void scr_decide_kernel(const int64_t* cells, const double* cell_val, ScrMisc* misc, int64_t nz, double thresh,

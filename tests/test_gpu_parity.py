@@ -341,6 +341,11 @@ def test_facade_final_system_test_known_answer(capsys):
     # PCM-native ingest: the raw uint8 samples give the same bits
     bits_u8, _, _ = rx.receive(g["wav_u8"])
     assert np.array_equal(bits_u8, bits)
+    # ... and so does the recording taken from host memory in pieces (Engine.receive_host, two packets per piece)
+    rx.host_chunk_samples = 1
+    bits_c, Hs_c, He_c = rx.receive(g["wav_u8"])
+    assert rx._last_ingest["chunks"] >= 2 and np.array_equal(bits_c, bits)
+    assert np.abs(Hs_c - Hstart).max() <= 1e-12 * np.abs(Hstart).max() and np.abs(He_c - Hend).max() <= 1e-12 * np.abs(Hend).max()
 
 
 def test_config1_64_frames():

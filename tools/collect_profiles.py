@@ -53,7 +53,7 @@ def counters(sub):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r02")
+    ap.add_argument("--tag", default="r03")
     args = ap.parse_args()
     os.makedirs(DST, exist_ok=True)
     shutil.copy(newest("trace/**/*_kernel_stats.csv"), os.path.join(DST, f"{args.tag}_kernel_stats.csv"))
@@ -90,7 +90,7 @@ def main():
         traffic[f"{k} grid={grid}"] = ent
     shares = {}
     for (k, grid), cs in sorted(sq.items()):
-        if "SQ_WAVE_CYCLES" not in cs or cs["SQ_WAVE_CYCLES"][1] < 100.0:
+        if "SQ_WAVE_CYCLES" not in cs or (cs["SQ_WAVE_CYCLES"][1] < 100.0 and not k.startswith("scr_")):
             continue
         wc = cs["SQ_WAVE_CYCLES"][0]
         ent = {"grid_threads": grid, "avg_us_under_pmc": round(cs["SQ_WAVE_CYCLES"][1], 1),
@@ -110,9 +110,20 @@ def main():
            "hbm_traffic_per_launch": traffic, "sq_shares": shares}
     json.dump(out, open(os.path.join(DST, f"{args.tag}_pmc.json"), "w"), indent=1)
     d = traffic[f"demod_kernel<2048, 1, false, 2> grid={big}"]
-    json.dump({"_comment": f"see {args.tag}_pmc.json", "calibration": out["calibration"],
-               "demod_kernel_bytes_per_launch_at_F": {str(F): d["hbm_bytes"]}},
-              open(os.path.join(DST, "traffic_current.json"), "w"), indent=1)
+    cur = {"_comment": f"see {args.tag}_pmc.json", "calibration": out["calibration"],
+           "demod_kernel_bytes_per_launch_at_F": {str(F): d["hbm_bytes"]}}
+    # one screened gf3_sync_stream call on the config-3 stream = one launch of each of these kernels (plus two scans and the
+    # suppression walk, which are noise): VALU wave-instructions (SQ pass) and HBM bytes (FETCH / WRITE passes) per call
+    call = ("scr_ring_kernel", "scr_ols_kernel", "scr_mlo_kernel", "scr_flag_kernel", "scr_scatter_kernel", "scr_refine_kernel",
+            "scr_decide_kernel", "scr_expand_kernel")
+    insts = sum(cs["SQ_INSTS_VALU"][0] for (k, grid), cs in sq.items() if k.split("<")[0] in call and "SQ_INSTS_VALU" in cs)
+    by = sum(cs["FETCH_SIZE"][0] * 1024 / cal_f + write[(k, grid)]["WRITE_SIZE"][0] * 1024 / cal_w
+             for (k, grid), cs in fetch.items() if k.split("<")[0] in call and (k, grid) in write)
+    if insts:
+        cur["stream_sync_valu_wave_instructions_per_call"] = insts
+    if by:
+        cur["stream_sync_hbm_bytes_per_call"] = by
+    json.dump(cur, open(os.path.join(DST, "traffic_current.json"), "w"), indent=1)
     for k, e in traffic.items():
         if "traffic_over_algorithmic" in e:
             print(f"{k:55s} HBM {e['hbm_bytes'] / 1e9:7.3f} GB = {e['traffic_over_algorithmic']:.3f} x algorithmic")

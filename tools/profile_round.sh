@@ -4,11 +4,12 @@
 # (separate --pmc passes, as the microarch guide prescribes) and one SQ pass (issue / wait / LDS shares of the hot kernels).
 set -o pipefail
 R=$PWD; OUT=$R/gpurun_out/round; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports it)}"
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu --no-power > $OUT/trace.log 2>&1; echo "trace rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-power > $OUT/fetch.log 2>&1; echo "fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-power > $OUT/write.log 2>&1; echo "write rc=$?"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-power --no-config5 --no-stream > $OUT/sq.log 2>&1; echo "sq rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu --no-power --no-h2d > $OUT/trace.log 2>&1; echo "trace rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-power --no-h2d > $OUT/fetch.log 2>&1; echo "fetch rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-power --no-h2d > $OUT/write.log 2>&1; echo "write rc=$?"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS --output-format csv -d $OUT/sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-power --no-config5 --no-h2d > $OUT/sq.log 2>&1; echo "sq rc=$?"
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/grbm -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu --no-power --no-config5 --no-stream > $OUT/grbm.log 2>&1; echo "grbm rc=$?"
 cd $R; ls $OUT

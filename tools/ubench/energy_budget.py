@@ -24,9 +24,10 @@ spec.loader.exec_module(bench)
 
 lib = C.CDLL(os.path.join(ROOT, "tools", "ubench", "libenergy.so"))
 lib.eb_spin.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double)]
-lib.eb_stream.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_double, C.POINTER(C.c_double)]
+lib.eb_stream.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_double)]
 SEC = float(os.environ.get("EB_SECONDS", "3.0"))
-OPS = {"fma64": 0, "add64": 1, "addu32": 2, "ldsr": 3, "ldsw": 4, "sleep": 5, "pad_only": 6}
+OPS = {"fma64": 0, "add64": 1, "addu32": 2, "ldsr": 3, "ldsw": 4, "sleep": 5, "pad_only": 6, "mul64": 7, "cndmask": 8, "mov": 9,
+       "salu": 10, "cvt": 11, "fma64_random": 12, "add64_random": 13, "mul64_random": 14, "ldsr_random": 15, "ldsw_random": 16}
 
 
 def powered(fn):
@@ -44,11 +45,11 @@ def spin(op, blocks, lds, pad, iters=100000):
     return {"op": op, "workgroups": blocks, "lds_bytes": lds, "pad_s_nop15": pad, "lane_ops_per_s": out[1], "clock_MHz": out[2], "package_w": w}
 
 
-def stream(name, buf, per_launch, wrap, blocks=2048):
+def stream(name, buf, per_launch, wrap, blocks=2048, random_data=0):
     out = (C.c_double * 2)()
-    rc, w = powered(lambda: lib.eb_stream(buf, per_launch, wrap, blocks, SEC, out))
+    rc, w = powered(lambda: lib.eb_stream(buf, per_launch, wrap, blocks, random_data, SEC, out))
     assert rc == 0, (name, rc)
-    return {"stream": name, "buffer_bytes": buf, "wrap_bytes_per_xcd": wrap, "bytes_per_s": out[1], "package_w": w}
+    return {"stream": name, "buffer_bytes": buf, "wrap_bytes_per_xcd": wrap, "random_data": bool(random_data), "bytes_per_s": out[1], "package_w": w}
 
 
 def main():
@@ -65,17 +66,21 @@ def main():
         P.append(spin("fma64", n_cu, one, pad))
     for pad in (0, 2, 4, 8, 16):
         P.append(spin("fma64", 2 * n_cu, two, pad))
-    for op in ("add64", "addu32"):
+    for op in ("fma64_random", "add64_random", "mul64_random"):
+        for pad in (0, 2, 8):
+            P.append(spin(op, 2 * n_cu, two, pad, iters=50000))
+    for op in ("add64", "addu32", "mul64", "cndmask", "mov", "salu", "cvt"):
         for pad in (0, 4):
             P.append(spin(op, 2 * n_cu, two, pad))
-    for op in ("ldsr", "ldsw"):
+    for op in ("ldsr", "ldsw", "ldsr_random", "ldsw_random"):
         for pad in (0, 4):
             P.append(spin(op, 2 * n_cu, two, pad, iters=30000))
     for cus in (n_cu // 4, n_cu // 2):
         P.append(spin("fma64", cus, one, 0))
     G = 1 << 30
-    res["streams"] = [stream("hbm", 16 * G, 16 * G, 0), stream("infinity_cache", 128 << 20, 16 * G, 16 << 20),
-                      stream("l2", 8 << 20, 16 * G, 1 << 20)]
+    res["streams"] = [stream("hbm", 16 * G, 16 * G, 0), stream("hbm_random", 16 * G, 16 * G, 0, random_data=1),
+                      stream("infinity_cache", 128 << 20, 16 * G, 16 << 20), stream("l2", 8 << 20, 16 * G, 1 << 20),
+                      stream("l2_random", 8 << 20, 16 * G, 1 << 20, random_data=1)]
     _, idle2 = powered(lambda: time.sleep(SEC))
     res["idle_after_w"] = idle2
     print(json.dumps(res, indent=1))
