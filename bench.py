@@ -10,7 +10,7 @@ Workload: N=4096, CP=512, P=2, D=8, QPSK on bins 1..2046, F frames per GPU (weak
 scaling), each frame a row of `stride` fp32 samples = [jitter gap 0..299 | chirp |
 2 pilots | 8 data | 2 pilots | pad], all distinct, synthesised on device by gf3_tx_frames.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 100 --warmup 5      (the defaults: a timed region of ~0.8 s)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --gpus N ...      (not under torchrun: starts its own N rank processes, see launch_ranks)
 
@@ -445,8 +445,8 @@ def launch_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=0,
                     help="frames per GPU (default: 65 536 at N=1 = BASELINE config 2; 131 072 at N>1 = config 4)")
     ap.add_argument("--stride", type=int, default=78720)

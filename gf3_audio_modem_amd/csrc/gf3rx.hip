@@ -1636,6 +1636,10 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     if (!cfg->const_re || !cfg->const_im || !cfg->const_bits || !cfg->known_re || !cfg->known_im || !cfg->data_bins)
         return fail(nullptr, GF3_EINVAL, "null table pointer");
     if (cfg->in_dtype < 0 || cfg->in_dtype > 3) return fail(nullptr, GF3_EINVAL, "bad in_dtype");
+#ifdef GF3_DEV_BUILD   /* developer iteration builds instantiate N = 4096 with f32 / f64 samples only: say so instead of launching the wrong kernel */
+    if (N != 4096 || cfg->in_dtype > GF3_F32)
+        return fail(nullptr, GF3_EINVAL, "developer build (-DGF3_DEV_BUILD): only N=4096 with f64 / f32 samples is instantiated (asked for N=%d, in_dtype=%d)", N, cfg->in_dtype);
+#endif
     gf3_ctx* c = new gf3_ctx();
     c->cfg = *cfg;
     if (hipGetDevice(&c->device) != hipSuccess) { delete c; return fail(nullptr, GF3_EHIP, "hipGetDevice failed: no usable GPU"); }

@@ -72,11 +72,10 @@ def test_gpu_tx_sync_demod_round_trip(N, F, storage, cp_frac, P, D, mu, lo_frac,
     o = eng.demod_frames(rows, starts, want=("slope",))
     bits = eng.unpack_bits(o["bits"]).cpu().numpy().reshape(-1)
     assert np.array_equal(bits, payload)
-    if N <= 4096:                                                      # and everything equals the oracle on these samples
-        x = rows.cpu().numpy().astype(np.float64).reshape(-1)
-        ref = orc.demod_frames(x, starts.cpu().numpy(), p)
-        assert np.array_equal(bits, ref["bits"].reshape(-1))
-        np.testing.assert_allclose(o["slope"].cpu().numpy(), ref["slope"], rtol=0, atol=1e-10)
+    x = rows.cpu().numpy().astype(np.float64).reshape(-1)              # and everything equals the oracle on these samples (every N)
+    ref = orc.demod_frames(x, starts.cpu().numpy(), p)
+    assert np.array_equal(bits, ref["bits"].reshape(-1))
+    np.testing.assert_allclose(o["slope"].cpu().numpy(), ref["slope"], rtol=0, atol=1e-10)
 
 
 @pytest.mark.gpu
@@ -116,4 +115,39 @@ def test_gpu_stream_sync_matches_oracle(N, F, cp_frac, storage, snr_db, seed):
         assert info["path"] in (0, 1)
     eng.sync_stream_mode(1)
     assert np.array_equal(eng.sync_stream(x).cpu().numpy(), want)
+    eng.close()
+
+
+@pytest.mark.gpu
+@settings(max_examples=12, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(N=st.sampled_from([1024, 2048]), F=st.integers(3, 7), storage=st.sampled_from(["float64", "float32", "int16", "uint8"]),
+       chunk_frames=st.floats(2.0, 4.5), snr_db=st.sampled_from([60.0, 20.0]), seed=st.integers(0, 2 ** 31 - 1))
+def test_gpu_host_ingest_equals_one_shot(N, F, storage, chunk_frames, snr_db, seed):
+    """Engine.receive_host (pieces of a random size, any sample storage, gaps and noise) gives the peaks and the bits of
+    the one-shot device path and of the oracle on the same (rounded) samples."""
+    import torch
+    from gf3_audio_modem_amd import Engine, RxConfig
+    p = _params(N, 1 / 8, 1, 2, 2, 0.0, 0.0)
+    dt = getattr(torch, storage)
+    rs = np.random.RandomState(seed)
+    payload = rs.randint(0, 2, F * p.D * p.C * p.mu)
+    fill = rs.choice(np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2), size=p.K - p.C)
+    r = orc.tx_stream(payload, fill, p, gaps=rs.randint(0, 400, F), lead=int(rs.randint(0, 3000)), tail=int(rs.randint(2, 500)))
+    r = r + rs.randn(len(r)) * np.sqrt(np.mean(r * r)) * 10 ** (-snr_db / 20)
+    if storage == "int16":
+        rq = np.round(r / np.abs(r).max() * 20000).astype(np.int16)
+    elif storage == "uint8":
+        rq = np.round(r / np.abs(r).max() * 100 + 128).astype(np.uint8)
+    else:
+        rq = r.astype(storage)
+    ref = orc.receive(rq.astype(np.float64), p)
+    cfg = RxConfig(N=p.N, CP=p.CP, P=p.P, D=p.D, data_bins=p.data_carriers, const_points=p.const_points, const_bits=p.const_bits,
+                   known_bits=p.known_bits, in_dtype=dt, fit_lo=p.fit_lo, fit_hi=p.fit_hi)
+    eng = Engine(cfg)
+    out = eng.receive_host(rq, chunk_samples=int(chunk_frames * p.frame_len))
+    assert np.array_equal(out["peaks"].cpu().numpy(), np.flatnonzero(ref["zeros"])), out["info"]
+    assert np.array_equal(eng.unpack_bits(out["bits"]).cpu().numpy(), ref["bits"]), out["info"]
+    x = torch.from_numpy(rq).cuda()
+    one = eng.sync_stream(x, mode=1)
+    assert torch.equal(one, out["peaks"]) and torch.equal(eng.demod_frames(x, (one + 2)[:-1])["bits"], out["bits"])
     eng.close()

@@ -74,7 +74,7 @@ def main():
     for N, leg in bench.get("roofline_rfft", {}).items():
         algo[f"rfft_kernel<{int(N[1:]) // 2}, 1>"] = leg["algorithmic_bytes_per_launch"]
     if "roofline_stream_sync" in bench:
-        algo["scr_ols_kernel<1>"] = bench["roofline_stream_sync"]["algorithmic_bytes_per_call"]
+        algo["scr_ring_kernel<1>"] = algo["scr_ols_kernel<1>"] = bench["roofline_stream_sync"]["hbm"]["algorithmic_bytes_per_call"]
     traffic = {}
     for (k, grid), cs in sorted(fetch.items()):
         if (k, grid) not in write or cs["FETCH_SIZE"][1] < 100.0:       # launches under 0.1 ms: set-up transforms, tiny lists

@@ -46,18 +46,20 @@ def slopes(eb):
     return resident, e, st
 
 
-def budget(name, mix, t_s, p_w, hbm_bytes, resident, e, st):
-    fp = lambda k, alt: e.get(k + "_random", e.get(k, alt))
+def budget(mix, t_s, hbm_bytes, resident, e, st, random_data):
+    """rows (label, wave-instructions, pJ per lane-operation, joule) with the prices measured on operands that carry
+    random bits (random_data) or on the structured operands of the plain loops (a handful of values shared by all lanes)"""
+    pick = lambda k, alt: e.get(k + "_random", e.get(k, alt)) if random_data else e.get(k, alt)
     other = mix["SQ_INSTS_VALU"] - sum(mix.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
                                                                 "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32",
                                                                 "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_FMA_F32"))
-    lds_e = 0.5 * (e.get("ldsr_random", e["ldsr"]) + e.get("ldsw_random", e["ldsw"]))
+    lds_e = 0.5 * (pick("ldsr", 52.0) + pick("ldsw", 61.0))
     rows = [
         ("resident grid (clocks, leakage, idle HBM): %.0f W x t" % resident, None, None, resident * t_s),
-        ("v_fma_f64", mix["SQ_INSTS_VALU_FMA_F64"], fp("fma64", 30.0), None),
-        ("v_add_f64", mix["SQ_INSTS_VALU_ADD_F64"], fp("add64", 20.0), None),
-        ("v_mul_f64", mix["SQ_INSTS_VALU_MUL_F64"], fp("mul64", 26.0), None),
-        ("v_rcp / v_rsq / v_sqrt f64 (priced as 4 fma)", mix["SQ_INSTS_VALU_TRANS_F64"], 4 * fp("fma64", 30.0), None),
+        ("v_fma_f64", mix["SQ_INSTS_VALU_FMA_F64"], pick("fma64", 30.0), None),
+        ("v_add_f64", mix["SQ_INSTS_VALU_ADD_F64"], pick("add64", 20.0), None),
+        ("v_mul_f64", mix["SQ_INSTS_VALU_MUL_F64"], pick("mul64", 26.0), None),
+        ("v_rcp / v_rsq / v_sqrt f64 (priced as 4 fma)", mix["SQ_INSTS_VALU_TRANS_F64"], 4 * pick("fma64", 30.0), None),
         ("f32 <-> f64 conversions", mix["SQ_INSTS_VALU_CVT"], e.get("cvt", 10.0), None),
         ("32-bit integer add / mul", mix["SQ_INSTS_VALU_INT32"], e.get("addu32", 15.0), None),
         ("64-bit integer", mix["SQ_INSTS_VALU_INT64"], 1.3 * e.get("addu32", 15.0), None),
@@ -71,11 +73,11 @@ def budget(name, mix, t_s, p_w, hbm_bytes, resident, e, st):
             joule = n * 64.0 * pj * 1e-12
         total += joule
         out.append((label, n, pj, joule))
-    e_hbm = st.get("hbm_random", st["hbm"])
+    e_hbm = st.get("hbm_random", st["hbm"]) if random_data else st["hbm"]
     j = hbm_bytes * e_hbm * 1e-12
-    out.append(("HBM -> registers, %.2f GB at %.0f pJ/B (streaming-read microbenchmark: L2 + fabric + HBM)" % (hbm_bytes / 1e9, e_hbm), None, None, j))
+    out.append(("HBM -> registers: %.2f GB (streaming-read microbenchmark: L2 + fabric + HBM)" % (hbm_bytes / 1e9), hbm_bytes / 64.0, e_hbm, j))
     total += j
-    return out, total, p_w * t_s
+    return out, total
 
 
 def main():
@@ -91,17 +93,25 @@ def main():
     print("pJ per byte streamed: %s" % {k: round(v, 1) for k, v in st.items()})
     F = 65536
     demod_bytes = list(tr["demod_kernel_bytes_per_launch_at_F"].values())[0]
-    corr_bytes = F * (4 * (23040 + 320 - 1) + 8)                  # algorithmic = measured to 0.5 % (profiles/r02_pmc.json)
+    corr_bytes = F * (4 * (23040 + 320 - 1) + 8)                  # algorithmic = measured to 0.5 % (profiles/r03_pmc.json)
     for kname, mkey, pkey, nbytes in (("demod_kernel<2048,f32,MODE_QPSK>", "demod_kernel<2048, 1, false, 2> grid=16777216", "demod_kernel", demod_bytes),
                                       ("corr_kernel<1024,f32>", "corr_kernel<1024, 1> grid=8388608", "corr_kernel", corr_bytes)):
-        rows, total, measured = budget(kname, mix[mkey], kp[pkey]["ms_per_launch"] * 1e-3, kp[pkey]["package_power_w"], nbytes, resident, e, st)
-        print("\n%s: %.3f ms per launch at %.0f W = %.3f J = %.1f uJ per packet" % (kname, kp[pkey]["ms_per_launch"], kp[pkey]["package_power_w"], measured, measured / F * 1e6))
-        for label, n, pj, joule in rows:
-            cnt = "" if n is None else "%8.1f M x 64 x %5.1f pJ" % (n / 1e6, pj)
-            line = ("| %s | %s | %.3f J | %.1f uJ | %.1f %% |" if args.md else "  %-100s %-28s %6.3f J  %6.1f uJ/packet  %5.1f %%") % (
-                label, cnt, joule, joule / F * 1e6, 100 * joule / measured)
-            print(line)
-        print("  modelled %.3f J = %.1f %% of the measured %.3f J; unattributed %.1f uJ per packet" % (total, 100 * total / measured, measured, (measured - total) / F * 1e6))
+        t_s, p_w = kp[pkey]["ms_per_launch"] * 1e-3, kp[pkey]["package_power_w"]
+        measured = p_w * t_s
+        lo_rows, lo = budget(mix[mkey], t_s, nbytes, resident, e, st, False)
+        hi_rows, hi = budget(mix[mkey], t_s, nbytes, resident, e, st, True)
+        print("\n%s: %.3f ms per launch at %.0f W = %.3f J = %.1f uJ per packet" % (kname, kp[pkey]["ms_per_launch"], p_w, measured, measured / F * 1e6))
+        if args.md:
+            print("| item | wave-instructions per launch | pJ per lane-op (structured ... random operands) | uJ per packet | share of measured |")
+            print("|---|---|---|---|---|")
+        for (label, n, pj0, j0), (_, _, pj1, j1) in zip(lo_rows, hi_rows):
+            cnt = "" if n is None or label.startswith("HBM") else "%.1f M" % (n / 1e6)
+            price = "" if pj0 is None else ("%.1f" % pj0 if abs(pj1 - pj0) < 0.05 else "%.1f ... %.1f" % (pj0, pj1)) + (" pJ/B" if label.startswith("HBM") else "")
+            uj = "%.1f" % (j0 / F * 1e6) if abs(j1 - j0) < 1e-9 else "%.1f ... %.1f" % (j0 / F * 1e6, j1 / F * 1e6)
+            sh = "%.1f %%" % (100 * j0 / measured) if abs(j1 - j0) < 1e-9 else "%.1f ... %.1f %%" % (100 * j0 / measured, 100 * j1 / measured)
+            print(("| %s | %s | %s | %s | %s |" if args.md else "  %-92s %10s  %-16s %-14s uJ/packet  %s") % (label, cnt, price, uj, sh))
+        tail = "modelled %.1f ... %.1f uJ per packet = %.1f ... %.1f %% of the measured %.1f uJ" % (lo / F * 1e6, hi / F * 1e6, 100 * lo / measured, 100 * hi / measured, measured / F * 1e6)
+        print(("| **%s** | | | | |" if args.md else "  %s") % tail)
 
 
 if __name__ == "__main__":
