@@ -104,6 +104,27 @@ class Gf3Error(RuntimeError):
     pass
 
 
+def host_pieces(n, chunk_samples, Lc, L):
+    """How Engine.receive_host cuts a stream of n samples (chirp length Lc, packet body L = M*S samples): a list of
+    pieces, each dict(lo, hi: the NEW samples [lo, hi) it brings; base: stream index of the first sample of its device
+    buffer, which starts with the last `carry` = Lc + L + 8 samples of the previous piece; n_buf; g_lo, g_hi: the lags
+    [g_lo, g_hi) of the stream's full convolution P (length n + Lc - 1) it owns).  Every lag 1 .. n+Lc-3 -- the p1 of
+    every zeros-index of OFDM.py:360 -- is owned by exactly one piece, with its Lc taps and both neighbours inside that
+    piece's buffer (or beyond the stream's true ends, where the convolution's zero extension is the reference's own).
+    Pure arithmetic: tested on the CPU (tests/test_abi_cpu.py)."""
+    carry = Lc + L + 8
+    H = max(int(chunk_samples), 2 * carry)
+    k = -(-n // H)
+    plen = n + Lc - 1
+    out = []
+    for c in range(k):
+        lo, hi = c * H, min(n, (c + 1) * H)
+        ce = min(carry, lo)
+        out.append(dict(lo=lo, hi=hi, base=lo - ce, n_buf=ce + hi - lo, g_lo=1 if c == 0 else lo - 1,
+                        g_hi=plen - 1 if c == k - 1 else hi - 1))
+    return out, H, carry
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -404,9 +425,8 @@ class Engine:
             raise ValueError("stream too short")
         pinned_in = x.is_pinned()
         Lc, L = cfg.chirp_length, cfg.M * cfg.S
-        carry = Lc + L + 8                                        # samples of the previous piece kept in front of a piece
-        H = max(int(chunk_samples), 2 * carry)
-        nchunks = -(-n // H)
+        pieces, H, carry = host_pieces(n, chunk_samples, Lc, L)  # carry: samples of the previous piece kept in front of a piece
+        nchunks = len(pieces)
         plen = n + Lc - 1
         dev = self.device
         main = torch.cuda.current_stream(dev)
@@ -432,12 +452,8 @@ class Engine:
         t_start = time.perf_counter()
 
         def geometry(c):
-            lo_s, hi_s = c * H, min(n, (c + 1) * H)
-            ce = min(carry, lo_s)
-            base = lo_s - ce
-            g_lo = 1 if c == 0 else lo_s - 1
-            g_hi = plen - 1 if c == nchunks - 1 else hi_s - 1
-            return lo_s, hi_s, ce, base, g_lo, g_hi
+            q = pieces[c]
+            return q["lo"], q["hi"], q["lo"] - q["base"], q["base"], q["g_lo"], q["g_hi"]
 
         def issue_copy(c):
             """host -> dev of piece c's new samples on the copy stream (after `ev_order` of the main stream)"""

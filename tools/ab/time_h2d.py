@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Where the time of Engine.receive_host goes on the config-3 stream from pinned memory: plain copies of several piece sizes,
+then the call at several piece sizes (GF3_LIB selects the build)."""
+import importlib.util, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+spec = importlib.util.spec_from_file_location("gf3_config3", os.path.join(ROOT, "tools", "config3.py"))
+tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
+eng, cfg, channel = tool.make_engine()
+r, payload = tool.make_stream(eng, channel, 4096)
+host = torch.empty(r.numel(), dtype=r.dtype).pin_memory(); host.copy_(r); torch.cuda.synchronize()
+n = host.numel()
+dst = torch.empty_like(r)
+for piece in (1 << 23, 1 << 25, 1 << 27, n):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for lo in range(0, n, piece):
+        dst[lo:lo + piece].copy_(host[lo:lo + piece], non_blocking=True)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print("plain copy in pieces of %10d samples: %.2f ms = %.1f GB/s" % (piece, dt * 1e3, n * 4 / dt / 1e9), flush=True)
+for chunk in (1 << 24, 1 << 25, 1 << 26, 1 << 27):
+    ts = []
+    for _ in range(4):
+        t = time.perf_counter(); res = eng.receive_host(host, chunk_samples=chunk); ts.append(time.perf_counter() - t)
+    t = float(np.median(ts[1:]))
+    print("receive_host chunk %10d: %.2f ms = %.1f GB/s, %.2f G samples/s, pieces %d" % (chunk, t * 1e3, n * 4 / t / 1e9, n / t / 1e9, res["info"]["chunks"]), flush=True)
+if os.environ.get("GF3_H2D_TRACE"):
+    print(json.dumps(res["info"]))
