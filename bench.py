@@ -419,6 +419,7 @@ def host_ingest_leg(eng, r, starts_one_shot, chunk_samples=1 << 25, reps=3):
                     "peaks_equal_one_shot": bool(torch.equal((res["peaks"] + 2)[:-1], starts_one_shot)),
                     "bits_equal_one_shot": bool(torch.equal(res["bits"], one)),
                     "second_look_chunks": info["second_look_chunks"], "second_look_packets": info["second_look_packets"],
+                    "seconds_setup_pieces_final": [info["setup_seconds"], info["pieces_seconds"], info["seconds"] - info["setup_seconds"] - info["pieces_seconds"]],
                     "note": "reported separately, never `value` (SURVEY 8d)"}}
 
 

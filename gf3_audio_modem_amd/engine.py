@@ -173,6 +173,7 @@ class Engine:
         self.max_window = int(self.lib.gf3_sync_max_window(h))
 
     def close(self):
+        self._tls = threading.local()                     # (drops the calling thread's cached ingest buffers)
         if getattr(self, "_h", None):
             self.lib.gf3_ctx_destroy(self._h)
             self._h = None
@@ -409,6 +410,7 @@ class Engine:
         (device, packed), info).  Raises ValueError where the reference fails (fewer than two detections; a packet that
         runs past the end of the stream)."""
         import time
+        t_start = time.perf_counter()
         cfg = self.cfg
         if isinstance(samples, torch.Tensor):
             if samples.is_cuda:
@@ -430,26 +432,35 @@ class Engine:
         plen = n + Lc - 1
         dev = self.device
         main = torch.cuda.current_stream(dev)
-        copier = torch.cuda.Stream(dev)
-        bufs = [self._new((carry + min(H, n),), cfg.in_dtype) for _ in range(min(2, nchunks))]
-        stage = None if pinned_in else [torch.empty((min(H, n),), dtype=cfg.in_dtype).pin_memory() for _ in range(min(2, nchunks))]
-        ev_copied = [torch.cuda.Event() for _ in bufs]
-        run_max = torch.full((1,), float("-inf"), dtype=torch.float64, device=dev)
         cap_list = int(list_cap or max(4096, 64 * (n // Lc + 2)))
-        idx_all = self._new((cap_list,), torch.int64)
-        val_all = self._new((cap_list, 3), torch.float64)
-        work = self._new((int(self.lib.gf3_sync_chunk_workspace_bytes(self._h, carry + min(H, n))),), torch.uint8)
         cap_peaks = n // Lc + 8
-        peaks_dev = self._new((cap_peaks,), torch.int64)
-        dwork = self._new((int(self.lib.gf3_sync_decide_workspace_bytes(self._h, cap_list)),), torch.uint8)
-        rows = self._new((cap_peaks, self.bytes_per_frame), torch.uint8)
+        nbuf = carry + min(H, n)
+        # Device buffers, workspace, pinned staging, the copy stream and its events are kept between calls (per host
+        # thread: two threads may ingest through one Engine at once) and reused while the sizes fit: a receiver that is
+        # fed one recording after another does not allocate per call.
+        key = (nbuf, cap_list, cap_peaks, bool(pinned_in), cfg.in_dtype, min(2, nchunks))
+        res = getattr(self._tls, "ingest", None)
+        if res is None or res["key"] != key:
+            res = dict(key=key, copier=torch.cuda.Stream(dev),
+                       bufs=[self._new((nbuf,), cfg.in_dtype) for _ in range(min(2, nchunks))],
+                       stage=None if pinned_in else [torch.empty((min(H, n),), dtype=cfg.in_dtype).pin_memory() for _ in range(min(2, nchunks))],
+                       idx_all=self._new((cap_list,), torch.int64), val_all=self._new((cap_list, 3), torch.float64),
+                       work=self._new((int(self.lib.gf3_sync_chunk_workspace_bytes(self._h, nbuf)),), torch.uint8),
+                       peaks_dev=self._new((cap_peaks,), torch.int64),
+                       dwork=self._new((int(self.lib.gf3_sync_decide_workspace_bytes(self._h, cap_list)),), torch.uint8),
+                       rows=self._new((cap_peaks, self.bytes_per_frame), torch.uint8))
+            res["ev_copied"] = [torch.cuda.Event() for _ in res["bufs"]]
+            self._tls.ingest = res
+        copier, bufs, stage, ev_copied = res["copier"], res["bufs"], res["stage"], res["ev_copied"]
+        idx_all, val_all, work, peaks_dev, dwork, rows = res["idx_all"], res["val_all"], res["work"], res["peaks_dev"], res["dwork"], res["rows"]
+        copier.wait_stream(main)                                  # (a previous call's consumers of these buffers are ordered before the new copies)
+        run_max = torch.full((1,), float("-inf"), dtype=torch.float64, device=dev)
         row_of, next_row = {}, 0                                  # zeros-index of a detection -> row of `rows` holding its packet's bits
         segs, overflow = [], []                                   # per piece: (first entry, entries) of the kept list; pieces whose list did not fit
         n_listed = 0
         BIG = (1 << 62)
         info = dict(chunks=nchunks, chunk_samples=H, overlap_samples=carry, pinned_input=bool(pinned_in), h2d_bytes=0,
                     second_look_chunks=0, second_look_packets=0, provisional_detections_dropped=0)
-        t_start = time.perf_counter()
 
         def geometry(c):
             q = pieces[c]
@@ -484,6 +495,7 @@ class Engine:
                                                  C.byref(cnt), _ptr(dwork), self._stream()))
             return peaks_dev[: cnt.value].cpu().numpy()
 
+        info["setup_seconds"] = time.perf_counter() - t_start    # (pinned staging, device buffers, workspace: cached by torch after the first call)
         issue_copy(0)
         for c in range(nchunks):
             b = c % 2
@@ -515,6 +527,8 @@ class Engine:
                 for k, i in enumerate(ready):
                     row_of[i] = next_row + k
                 next_row += len(ready)
+
+        info["pieces_seconds"] = time.perf_counter() - t_start - info["setup_seconds"]
 
         # ---- the end of the stream: the maximum is final
         def piece_on_device(c):

@@ -23,6 +23,8 @@ for chunk in (1 << 24, 1 << 25, 1 << 26, 1 << 27):
     for _ in range(4):
         t = time.perf_counter(); res = eng.receive_host(host, chunk_samples=chunk); ts.append(time.perf_counter() - t)
     t = float(np.median(ts[1:]))
-    print("receive_host chunk %10d: %.2f ms = %.1f GB/s, %.2f G samples/s, pieces %d" % (chunk, t * 1e3, n * 4 / t / 1e9, n / t / 1e9, res["info"]["chunks"]), flush=True)
+    i = res["info"]
+    print("receive_host chunk %10d: %.2f ms = %.1f GB/s, %.2f G samples/s, pieces %d (last call: setup %.2f, pieces %.2f, total %.2f ms)" % (
+        chunk, t * 1e3, n * 4 / t / 1e9, n / t / 1e9, i["chunks"], i["setup_seconds"] * 1e3, i["pieces_seconds"] * 1e3, i["seconds"] * 1e3), flush=True)
 if os.environ.get("GF3_H2D_TRACE"):
     print(json.dumps(res["info"]))
