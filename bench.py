@@ -271,6 +271,26 @@ def _event_ms(fn, reps=20, warm=3):
     return float(np.median([a.elapsed_time(b) for a, b in evs]))
 
 
+def measured_copy_bandwidth(dev, gib=4, reps=20):
+    """"also report against the measured copy-kernel bandwidth" -- a device-to-device copy of `gib` GiB
+    (far past the Infinity Cache), bytes read + bytes written per second, median of 20 after 3 warm-ups."""
+    n = gib << 28                                           # float32 elements
+    src = torch.empty(n, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    ms = _event_ms(lambda: dst.copy_(src), reps)
+    del src, dst
+    return {"GB_per_s": 2 * n * 4 / ms / 1e6, "what": f"torch device-to-device copy of {gib} GiB: bytes read + written per second, median of {reps} after 3 warm-ups"}
+
+
+def add_copy_fraction(obj, copy_gbs):
+    """frac_of_measured_copy next to every `frac` of an HBM-bound roofline entry (nested dicts included)"""
+    if isinstance(obj, dict):
+        if obj.get("bound") == "hbm" and obj.get("achieved") is not None and obj.get("unit") == "GB/s":
+            obj["frac_of_measured_copy"] = obj["achieved"] / copy_gbs
+        for v in list(obj.values()):
+            add_copy_fraction(v, copy_gbs)
+
+
 def config5_rooflines(dev, log2_samples=28, log2_symbols=26, reps=20):
     """BASELINE config 5, sized past the 256 MB Infinity Cache so that the figure is an HBM figure: per N in
     {1024, 2048, 4096, 8192} ONE launch of rfft_kernel over 2^28 f32 samples (1 GiB in, 2.1 GB of complex128 bins
@@ -376,7 +396,7 @@ def stream_sync_roofline(dev, frames=4096, pmc=None, h2d=True):
                                     "unit": "G wave-instr/s", "frac": (insts / t / VALU_PEAK_WAVE_INSTR_PER_S) if insts else None,
                                     "valu_wave_instructions_per_call": insts,
                                     "counter_source": "profiles/traffic_current.json (SQ_INSTS_VALU pass of this command; not measured in this run)" if insts else None,
-                                    "hbm": {"achieved": by / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS,
+                                    "hbm": {"bound": "hbm", "achieved": by / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / t / 1e9 / HBM_PEAK_GBS,
                                             "algorithmic_bytes_per_call": by, "traffic": traffic},
                                     "call_ms": t * 1e3, "fp64_path_ms": res["sync_stream_fp64_path_s"] * 1e3, "demod_ms": res["demod_s"] * 1e3,
                                     "timing": res["timing"],
@@ -659,6 +679,7 @@ def main():
             extra.update(config5_rooflines(dev))
         if not args.no_stream:
             extra.update(stream_sync_roofline(dev, pmc=pmc, h2d=not args.no_h2d))
+        extra["hbm_copy_measured"] = measured_copy_bandwidth(dev)
 
     if rank == 0:
         from gf3_audio_modem_amd import _lib
@@ -704,6 +725,8 @@ def main():
                               "algorithmic_bytes_per_launch": bytes_sync, "avg_launch_ms": t_sync * 1e3},
         }
         out.update(extra)
+        if "hbm_copy_measured" in out:
+            add_copy_fraction(out, out["hbm_copy_measured"]["GB_per_s"])
         if world == 1 and not multi and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(cfg, big, payload, args.window, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -1377,8 +1377,7 @@ struct gf3_ctx {
     // single-precision screening plan of the stream-mode sync (gf3rx_screen.h); ok = false: always the fp64 path
     struct { bool ok = false; int Q = 0, H = 0; cf *d_tw = nullptr, *d_twn = nullptr; float4* d_Hs = nullptr;
              float *d_H0N = nullptr, *d_Hinf = nullptr;
-             bool ring = false; float4* d_Hb = nullptr; float* d_ecoef = nullptr; int R_forced = 0;
-             double* d_chirp_t = nullptr; } scr;      // the chirp's taps tiled for scr_refine2_kernel (GF3_REFINE_TAPS)   // band-limited kernel (scr_ring_kernel)
+             bool ring = false; float4* d_Hb = nullptr; float* d_ecoef = nullptr; int R_forced = 0; } scr;   // band-limited kernel (scr_ring_kernel)
     // The ONLY field a call may write after gf3_ctx_create: the default evaluation mode of the legacy entry point
     // gf3_sync_stream (gf3_sync_stream_mode sets it; gf3_sync_stream_ex takes the mode per call and never reads it).
     // 0: by stream length (screen from GF3_SCR_MIN_SAMPLES on); 1: fp64 only; 2: screen whenever a plan exists; 3: as 2 with the general kernel
@@ -1608,20 +1607,6 @@ static int build_screen_plan(gf3_ctx* c) {
     HIPCHK(c, upload(&sp.d_Hinf, Hinf.data(), Hinf.size()));
     HIPCHK(c, upload((float**)&sp.d_Hb, Hb.data(), Hb.size()));
     HIPCHK(c, upload(&sp.d_ecoef, ecoef.data(), ecoef.size()));
-#if GF3_REFINE_TAPS
-    {   // chirp_t[(step TAPS + q) 64 + lane] = c[step 64 TAPS + TAPS lane + q], zero beyond Lc
-        constexpr int TP = GF3_REFINE_TAPS, WT = 64 * TP;
-        const int nst = (c->Lc + WT - 1) / WT;
-        std::vector<double> ct((size_t)nst * WT, 0.0);
-        for (int st = 0; st < nst; ++st)
-            for (int q = 0; q < TP; ++q)
-                for (int l = 0; l < 64; ++l) {
-                    const int k = st * WT + TP * l + q;
-                    if (k < c->Lc) ct[((size_t)st * TP + q) * 64 + l] = c->chirp[k];
-                }
-        HIPCHK(c, upload(&sp.d_chirp_t, ct.data(), ct.size()));
-    }
-#endif
     sp.ok = true;
     return GF3_OK;
 }
@@ -1841,7 +1826,7 @@ extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
     DeviceGuard dg(c);
     void* ptrs[] = {c->d_tw_x[0], c->d_twn_x[0], c->d_tw_x[1], c->d_twn_x[1], c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
                     c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_known_time,
-                    c->scr.d_tw, c->scr.d_twn, c->scr.d_Hs, c->scr.d_H0N, c->scr.d_Hinf, c->scr.d_Hb, c->scr.d_ecoef, c->scr.d_chirp_t};
+                    c->scr.d_tw, c->scr.d_twn, c->scr.d_Hs, c->scr.d_H0N, c->scr.d_Hinf, c->scr.d_Hb, c->scr.d_ecoef};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete c;
 }
@@ -2237,11 +2222,7 @@ static int sync_stream_screened(const gf3_ctx* c, const void* d_r, int64_t n, co
         const int64_t slots = 2 * (int64_t)c->n_cu;                         // (the LDS staging allows two workgroups per CU)
         const int64_t wgs = (w.s_cap + 3) / 4;                               // (a wave per cell at a time)
         const unsigned grid = (unsigned)(wgs < slots ? wgs : slots);
-#if GF3_REFINE_TAPS
-        const int64_t wg8 = 8 * slots;                                       // (occupancy is set by registers: up to four workgroups per CU, a wave per cell)
-        DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine2_kernel<DTC, GF3_REFINE_TAPS>), dim3((unsigned)(wg8 < wgs ? wg8 : wgs)), dim3(SCR_REF_THREADS), 0, st, a, (const double*)sp.d_chirp_t));
-        (void)grid;
-#elif GF3_REFINE_MFMA
+#if GF3_REFINE_MFMA
         const int64_t wg4 = 4 * slots;                                       // (no LDS staging: more resident waves, a wave per cell)
         DISPATCH_DT(dt, hipLaunchKernelGGL((scr_refine_mfma_kernel<DTC>), dim3((unsigned)(wg4 < wgs ? wg4 : wgs)), dim3(SCR_REF_THREADS), 0, st, a));
         (void)grid;

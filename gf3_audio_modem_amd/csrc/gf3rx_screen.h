@@ -26,7 +26,6 @@
 // plus the packed-real split per transform: g <~ 60 u.  The kernel uses GF3_SCR_GAMMA = 256 u; tests/ measure the
 // realised ratio on random, DC-biased and adversarial streams (it stays below 2 u).
 #pragma once
-#include <type_traits>
 #include "gf3rx_device.h"
 
 typedef float2 cf;
@@ -931,114 +930,6 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
         }
         if (nx >= ncell) break;                        // (uniform)
         cur = nx; cur_cell = nx_cell; st = 0;
-    }
-}
-
-// The same re-evaluation with the TAPS read straight from a table laid out for it.  scr_refine_kernel stages both the
-// samples and the taps of a step through LDS (as doubles), which is what limits it to two workgroups per CU.  The taps are the
-// same for every cell, so the context keeps them pre-tiled -- chirp_t[(step TAPS + q) 64 + lane] = c[step 64 TAPS + TAPS lane + q]
-// -- and a lane's TAPS taps of a step are TAPS coalesced 8-byte loads into registers, no LDS.  Only the samples go through LDS,
-// raw (4 bytes each unless the stream is f64), element e at e + (e >> 4) as before: a lane reads its TAPS + 15 samples at a
-// stride of 17 words, conflict-free, and widens them on the way.  LDS per workgroup falls from 70 KB to 9-18 KB, so the
-// register count alone sets the occupancy (TAPS = 8: 16 lags x 8 taps per lane and step, three or four waves per SIMD).
-#ifndef GF3_REFINE_WPS
-#define GF3_REFINE_WPS 2            /* waves per SIMD scr_refine2_kernel is compiled for */
-#endif
-#ifndef GF3_REFINE_TAPS
-#define GF3_REFINE_TAPS 0          /* 0: scr_refine_kernel; 8 / 16: scr_refine2_kernel with that many taps per lane and step */
-#endif
-template <int DT, int TAPS>
-__global__ __launch_bounds__(SCR_REF_THREADS, GF3_REFINE_WPS) void scr_refine2_kernel(RefineArgs a, const double* __restrict__ chirp_t) {
-    constexpr int WT = 64 * TAPS, NW = SCR_REF_THREADS / 64, NQ = TAPS;               // samples / taps per lane and step
-    typedef typename RawT<DT>::E E;
-    typedef typename std::conditional<DT == DT_F64, double, float>::type S;          // what the staging area holds (exact for i16 / u8)
-    __shared__ S xs_all[NW][WT + 16 + (WT + 16) / 16 + 1];
-    if (a.misc->status & 1) return;
-    auto first_lane64 = [](unsigned long long v) -> long long {
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return (long long)(((unsigned long long)hi << 32) | lo);
-    };
-    const long long ncell = first_lane64((unsigned long long)a.misc->ncell);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    S* xs = xs_all[wave];
-    const int nst = (a.Lc + WT - 1) / WT;                                             // steps per cell
-    const long long nwaves = (long long)gridDim.x * NW;
-    // cells are dealt to the waves by a fixed stride (every cell costs the same): a counted loop over wave-uniform scalars.
-    // The samples of a step are requested TWO steps ahead and its taps one step ahead (a step's 8 x 16 fma per lane take less
-    // than a trip to HBM).
-    for (long long cur = (long long)blockIdx.x * NW + wave; cur < ncell; cur += nwaves) {
-        const int64_t cell = (int64_t)first_lane64((unsigned long long)a.cells[cur]);
-        const int64_t i00 = GF3_SCR_CELL * cell - (a.Lc - 1);
-        double acc[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-        S xr[2][NQ + 1];
-        double ctn[NQ];
-        auto fetch = [&](S (&dst)[NQ + 1], int st) {
-            const int64_t i0 = i00 + (int64_t)st * WT;
-            if (i0 >= 0 && i0 + WT + 15 <= a.n_in) {                                  // (uniform) the whole step lies inside the stream
-                const E* base = (const E*)a.in + i0 + lane;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) dst[q] = (S)base[64 * q];
-                dst[NQ] = (S)((const E*)a.in + i0)[WT + (lane < 15 ? lane : 14)];
-            } else {
-                const int64_t last_i = a.n_in - 1;
-#pragma unroll
-                for (int q = 0; q < NQ + 1; ++q) {
-                    const int64_t i = i0 + lane + 64 * q;
-                    const int64_t ic = i < 0 ? 0 : (i > last_i ? last_i : i);
-                    const E val = ((const E*)a.in)[ic];
-                    dst[q] = (i == ic) ? (S)val : (S)0;
-                }
-            }
-        };
-        auto taps = [&](int st) {
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) ctn[q] = chirp_t[((int64_t)st * NQ + q) * 64 + lane];
-        };
-        fetch(xr[0], 0);
-        if (nst > 1) fetch(xr[1], 1);
-        taps(0);
-        auto step = [&](S (&cur_x)[NQ + 1], int st) {
-#pragma unroll
-            for (int q = 0; q < NQ + 1; ++q) { const int e = lane + 64 * q; if (q < NQ || lane < 15) xs[e + (e >> 4)] = cur_x[q]; }
-            asm volatile("" ::: "memory");
-            double ct[NQ];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) ct[q] = ctn[q];
-            if (st + 2 < nst) fetch(cur_x, st + 2);                                    // (its registers have just been written out)
-            if (st + 1 < nst) taps(st + 1);
-            double x[NQ + 15];
-#pragma unroll
-            for (int i = 0; i < NQ + 15; ++i) { const int e = NQ * lane + i; x[i] = (double)xs[e + (e >> 4)]; }
-#pragma unroll
-            for (int kk = 0; kk < NQ; ++kk)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] = fma(ct[kk], x[kk + j], acc[j]);
-            asm volatile("" ::: "memory");
-        };
-        for (int st = 0; st < nst; st += 2) {
-            step(xr[0], st);
-            if (st + 1 < nst) step(xr[1], st + 1);
-        }
-        // ---- the cell is complete: sum the 16 partial sums over the wave, keep them
-        const int64_t m0 = GF3_SCR_CELL * cell;
-        double mine = 0.0, mx = -INFINITY;
-        bool nan = false;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            double sum = acc[j];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
-            mine = (lane == j) ? sum : mine;
-            if (m0 + j < a.plen) { mx = fmax(mx, sum); nan = nan || !(sum == sum); }
-        }
-        if (lane < 16) a.cell_val[cur * 16 + lane] = mine;
-        if (lane == 0) {
-            if (nan) atomicOr(&a.misc->m_nan, 1u);
-            else if (mx > -INFINITY) atomicMax(&a.misc->m_key, scr_key(mx));
-        }
     }
 }
 
