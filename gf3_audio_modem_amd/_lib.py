@@ -48,7 +48,7 @@ _SIGS = {
                                      C.c_void_p, C.c_void_p, C.c_int32, c_i64_p, C.c_void_p]),
     "gf3_sync_chunk_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64]),
     "gf3_sync_chunk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.c_int64, c_i64_p, C.c_void_p, C.c_void_p]),
+                                 C.c_void_p, C.c_int64, c_i64_p, c_double_p, C.c_void_p, C.c_void_p]),
     "gf3_sync_decide_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64]),
     "gf3_sync_decide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                   c_i64_p, C.c_void_p, C.c_void_p]),

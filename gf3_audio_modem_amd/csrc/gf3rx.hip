@@ -2381,7 +2381,7 @@ __global__ __launch_bounds__(CK_THREADS) void ck_max_kernel(const double* __rest
     const int anynan = __syncthreads_or(nan ? 1 : 0);                   // np.amax propagates NaN (OFDM.py:359)
     if (threadIdx.x == 0) part[blockIdx.x] = anynan ? NAN : mx;
 }
-// run_max = amax(run_max, part[0..n)) with NumPy's NaN rule
+// run_max[0] = amax(run_max[0], part[0..n)) with NumPy's NaN rule; run_max[1] = amax(part[0..n)): this piece's own maximum
 __global__ void ck_fold_max(const double* part, int n, double* run_max) {
     __shared__ double scratch[16];
     double mx = -INFINITY;
@@ -2392,6 +2392,7 @@ __global__ void ck_fold_max(const double* part, int n, double* run_max) {
     if (threadIdx.x == 0) {
         const double run = run_max[0];
         run_max[0] = (anynan || !(run == run)) ? NAN : fmax(run, mx);
+        run_max[1] = anynan ? NAN : mx;
     }
 }
 // pass 0 (offsets == nullptr): count per block; pass 1: write zeros-index g - 1 + lag_offset and the raw triple of every
@@ -2461,7 +2462,7 @@ extern "C" int64_t gf3_sync_chunk_workspace_bytes(const gf3_ctx* c, int64_t n) {
 
 extern "C" int gf3_sync_chunk(const gf3_ctx* c, const void* d_buf, int64_t n, int64_t lag_lo, int64_t lag_hi, int64_t lag_offset,
                               double* d_run_max, int64_t* d_idx, double* d_val3, int64_t cap, int64_t* n_listed,
-                              void* d_work, void* stream) {
+                              double* h_piece_max, void* d_work, void* stream) {
     DeviceGuard dg(c);
     if (!c || !d_buf || !d_run_max || !d_idx || !d_val3 || !n_listed || !d_work || n < 3 || cap < 0)
         return fail(c, GF3_EINVAL, "gf3_sync_chunk: bad argument");
@@ -2469,6 +2470,7 @@ extern "C" int gf3_sync_chunk(const gf3_ctx* c, const void* d_buf, int64_t n, in
     if (lag_lo < 1 || lag_hi > w.plen - 1 || lag_lo > lag_hi)
         return fail(c, GF3_EINVAL, "gf3_sync_chunk: lags [%lld, %lld) outside [1, %lld)", (long long)lag_lo, (long long)lag_hi, (long long)(w.plen - 1));
     *n_listed = 0;
+    if (h_piece_max) *h_piece_max = -INFINITY;
     if (lag_lo == lag_hi) return GF3_OK;
     hipStream_t st = (hipStream_t)stream;
     char* base = (char*)d_work;
@@ -2512,9 +2514,12 @@ extern "C" int gf3_sync_chunk(const gf3_ctx* c, const void* d_buf, int64_t n, in
     hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, nb, offs, total, (const long long*)nullptr, (const long long*)nullptr);
     HIPCHK(c, hipGetLastError());
     int64_t want = 0;
+    double pmax = -INFINITY;
     HIPCHK(c, hipMemcpyAsync(&want, total, 8, hipMemcpyDeviceToHost, st));
+    if (h_piece_max) HIPCHK(c, hipMemcpyAsync(&pmax, d_run_max + 1, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     *n_listed = want;
+    if (h_piece_max) *h_piece_max = pmax;
     if (want > cap) return fail(c, GF3_ERANGE, "gf3_sync_chunk: %lld lags to keep exceed capacity %lld", (long long)want, (long long)cap);
     if (want > 0) {
         hipLaunchKernelGGL(ck_list_kernel, dim3((unsigned)nb), dim3(PK_THREADS), 0, st, (const double*)P, lag_lo, lag_hi, (const double*)d_run_max,

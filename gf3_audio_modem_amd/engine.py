@@ -454,7 +454,7 @@ class Engine:
         copier, bufs, stage, ev_copied = res["copier"], res["bufs"], res["stage"], res["ev_copied"]
         idx_all, val_all, work, peaks_dev, dwork, rows = res["idx_all"], res["val_all"], res["work"], res["peaks_dev"], res["dwork"], res["rows"]
         copier.wait_stream(main)                                  # (a previous call's consumers of these buffers are ordered before the new copies)
-        run_max = torch.full((1,), float("-inf"), dtype=torch.float64, device=dev)
+        run_max = torch.full((2,), float("-inf"), dtype=torch.float64, device=dev)     # [maximum so far, the last piece's own maximum]
         row_of, next_row = {}, 0                                  # zeros-index of a detection -> row of `rows` holding its packet's bits
         segs, overflow = [], []                                   # per piece: (first entry, entries) of the kept list; pieces whose list did not fit
         n_listed = 0
@@ -481,13 +481,14 @@ class Engine:
             info["h2d_bytes"] += (hi_s - lo_s) * x.element_size()
 
         def sync_piece(buf, n_buf, lag_lo, lag_hi, base, idx_t, val_t, cap):
-            cnt = C.c_int64(0)
+            """-> (entries listed, or -(entries wanted) - 1 when they do not fit; the piece's own maximum)"""
+            cnt, pmax = C.c_int64(0), C.c_double(0.0)
             rc = self.lib.gf3_sync_chunk(self._h, _ptr(buf), n_buf, lag_lo, lag_hi, base, _ptr(run_max), _ptr(idx_t), _ptr(val_t),
-                                         cap, C.byref(cnt), _ptr(work), self._stream())
+                                         cap, C.byref(cnt), C.byref(pmax), _ptr(work), self._stream())
             if rc == _lib.GF3_ERANGE:
-                return -int(cnt.value) - 1
+                return -int(cnt.value) - 1, pmax.value
             self._check(rc)
-            return int(cnt.value)
+            return int(cnt.value), pmax.value
 
         def decide(idx_t, val_t, k, nz):
             cnt = C.c_int64(0)
@@ -510,18 +511,24 @@ class Engine:
                 copier.wait_event(ev_order)
                 issue_copy(c + 1)                                  # runs under this piece's kernels
             buf = bufs[b][carry - ce: carry + (hi_s - lo_s)]
-            got = sync_piece(buf, buf.numel(), g_lo - base, g_hi - base, base, idx_all[n_listed:], val_all[n_listed:], cap_list - n_listed)
+            got, pmax = sync_piece(buf, buf.numel(), g_lo - base, g_hi - base, base, idx_all[n_listed:], val_all[n_listed:], cap_list - n_listed)
             if got < 0:
-                overflow.append(c)                                 # (no positive maximum yet, or a threshold too low to be selective here)
+                # no positive maximum yet (leading silence), or one so small that most lags of this piece stay above 0.4 x
+                # it (leading noise): nothing is kept of the piece but its own maximum, which at the end decides whether it
+                # has to be looked at again at all
+                overflow.append((c, pmax))
                 segs.append((n_listed, 0))
-                continue
-            segs.append((n_listed, got))
-            n_listed += got
-            if overflow:
-                continue                                           # provisional decisions would miss that piece's candidates: left to the end
+            else:
+                segs.append((n_listed, got))
+                n_listed += got
+            # provisional decision with the maximum so far (a piece that kept nothing is simply not represented: whatever
+            # that gets wrong is put right at the end), then the packets whose samples are resident
             pk = decide(idx_all, val_all, n_listed, BIG)
-            ready = [int(i) for i in pk if int(i) not in row_of and int(i) + 2 >= base and int(i) + 2 + L <= hi_s]
+            k0 = int(np.searchsorted(pk, base - 2))                # (detections before this buffer were handled, or wait for the end)
+            ready = [int(i) for i in pk[k0:] if int(i) + 2 + L <= hi_s and int(i) not in row_of]
             if ready:
+                if next_row + len(ready) > rows.shape[0]:           # (provisional detections that are dropped later use rows too)
+                    rows = torch.cat([rows, self._new((max(len(ready), rows.shape[0]), self.bytes_per_frame), torch.uint8)])
                 st = torch.tensor([i + 2 - base for i in ready], dtype=torch.int64, device=dev)
                 self.demod_frames(buf, st, out_bits=rows[next_row: next_row + len(ready)])
                 for k, i in enumerate(ready):
@@ -539,11 +546,15 @@ class Engine:
             return buf, base, g_lo, g_hi
 
         extra = {}
-        for c in overflow:
+        M = float(run_max[0].item())
+        for c, pmax in overflow:
+            if np.isfinite(M) and M > 0.0 and pmax < cfg.thresh * M * (1.0 - 1e-6):
+                info["overflow_pieces_below_threshold"] = info.get("overflow_pieces_below_threshold", 0) + 1
+                continue                                           # no lag of that piece can pass thresh x (final maximum): nothing to look at
             buf, base, g_lo, g_hi = piece_on_device(c)
             k = g_hi - g_lo
             it, vt = self._new((k,), torch.int64), self._new((k, 3), torch.float64)
-            got = sync_piece(buf, buf.numel(), g_lo - base, g_hi - base, base, it, vt, k)
+            got, _ = sync_piece(buf, buf.numel(), g_lo - base, g_hi - base, base, it, vt, k)
             extra[c] = (it[:got], vt[:got])
             info["second_look_chunks"] += 1
         if overflow:
@@ -584,7 +595,7 @@ class Engine:
         bits = rows[order]
         torch.cuda.synchronize(dev)
         info["seconds"] = time.perf_counter() - t_start
-        info["max"] = float(run_max.item())
+        info["max"] = M
         return dict(peaks=torch.from_numpy(peaks).to(dev), bits=bits, info=info)
 
     # ------------------------------------------------------------------ bit helpers (layout only)

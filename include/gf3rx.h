@@ -207,8 +207,10 @@ int gf3_sync_stream_info(const gf3_ctx *ctx, int64_t *h_out4);
  * previous piece in front of it (none at the stream's start) -- restricted to the lags [lag_lo, lag_hi) of the buffer's
  * own full convolution P_buf[m] = sum_k buf[m-Lc+1+k] chirp[k] (1 <= lag_lo <= lag_hi <= n+Lc-2; the caller chooses
  * them so that every lag of the stream is owned by exactly one piece and its taps and both neighbours are complete).
- *   *d_run_max (device): in  = maximum of the earlier pieces (-inf before the first), NumPy's NaN rule;
- *                        out = maximum including this piece's lags
+ *   d_run_max (device, TWO doubles): [0] in  = maximum of the earlier pieces (-inf before the first), NumPy's NaN rule;
+ *                                        out = maximum including this piece's lags;   [1] out = this piece's own maximum
+ *   *h_piece_max (host, optional): that own maximum -- a piece whose list overflowed needs no second look if its own
+ *                        maximum stays below thresh * (final maximum) * (1 - 1e-6): none of its lags can pass
  *   listed: every owned lag g with P[g] >= thresh * run_max * (1 - 1e-6) (every owned lag while run_max is not a
  *           positive finite number): d_idx[k] = g - 1 + lag_offset (the zeros-index of OFDM.py:360 in the caller's
  *           global numbering), d_val3[3k..3k+2] = P[g-1], P[g], P[g+1]; ascending; *n_listed (host) = how many.
@@ -220,7 +222,7 @@ int64_t gf3_sync_chunk_workspace_bytes(const gf3_ctx *ctx, int64_t n);
 int gf3_sync_chunk(const gf3_ctx *ctx, const void *d_buf, int64_t n,
                    int64_t lag_lo, int64_t lag_hi, int64_t lag_offset,
                    double *d_run_max, int64_t *d_idx, double *d_val3, int64_t cap,
-                   int64_t *n_listed, void *d_work, void *stream);
+                   int64_t *n_listed, double *h_piece_max_or_null, void *d_work, void *stream);
 /*
  * gf3_sync_decide: the reference's rule on the listed raw values -- p = P / *d_max first, candidate <=>
  * (p1-p0)(p2-p1) <= 0 and p1 > thresh (OFDM.py:359-361) -- then the suppression walk over Lc samples with the

@@ -1116,7 +1116,7 @@ def test_receive_host_chunked_equals_one_shot_and_reference(storage):
     assert out1["info"]["chunks"] == 1 and torch.equal(out1["peaks"], one) and torch.equal(out1["bits"], bits_one)
 
 
-def _crafted_stream(p, lead_zeros):
+def _crafted_stream(p, lead_zeros, lead_noise=0.0):
     """[lead | weak bare chirp W1 (0.3) overlapping the chirp of packet 0 sent at HALF amplitude | 21 000 zeros |
     packets 1..5 at full amplitude | terminating chirp | tail].  While only the first piece has been seen the maximum
     is packet 0's (0.5): W1 (0.3 / 0.5 = 0.6 > 0.4) is a candidate, comes first and suppresses packet 0's chirp, which
@@ -1131,19 +1131,23 @@ def _crafted_stream(p, lead_zeros):
     s = np.concatenate([np.zeros(lead_zeros + Lc // 2), 0.5 * rows[0], np.zeros(21000), rows[1:].reshape(-1), chirp, np.zeros(40)])
     s[lead_zeros: lead_zeros + Lc] += 0.3 * chirp / 0.2 * 0.2            # W1 starts Lc/2 before packet 0's chirp
     s[lead_zeros:] += 1e-5 * rs.randn(len(s) - lead_zeros)              # (the lead-in stays EXACTLY zero: no positive maximum there)
+    if lead_noise:
+        s[:lead_zeros] = lead_noise * rs.randn(lead_zeros)               # ... or holds noise only: a noise-sized maximum
     return s, payload
 
 
-@pytest.mark.parametrize("lead_zeros,list_cap", [(50, None), (50, 4), (45000, None)])
-def test_receive_host_later_piece_changes_earlier_decisions(lead_zeros, list_cap):
+@pytest.mark.parametrize("lead_zeros,list_cap,lead_noise", [(50, None, 0.0), (50, 4, 0.0), (45000, None, 0.0), (45000, 64, 1e-3)])
+def test_receive_host_later_piece_changes_earlier_decisions(lead_zeros, list_cap, lead_noise):
     """The hard case of the global-max rule (OFDM.py:359): a later piece raises the maximum, which kills a candidate
     the first piece had accepted AND thereby un-suppresses another one -- a detection the provisional pass never
     demodulated (second look at that packet).  With 45 000 leading zeros the first piece has no positive maximum at
-    all, so every one of its lags stays listed, the list overflows and the piece itself is looked at again; a small
-    list capacity forces the same path on the ordinary stream.  Expected: exactly the oracle's detections and bits."""
+    all, so every one of its lags qualifies and the list overflows; with leading noise (and a small list) it overflows
+    on a noise-sized maximum: either way only the piece's own maximum is kept, and as it cannot reach 0.4 x the final
+    maximum the piece is never looked at again.  A list capacity of 4 on the ordinary stream overflows on pieces that DO
+    hold chirps: those are copied and listed again at the end.  Expected: exactly the oracle's detections and bits."""
     g = load("g1_n1024_qpsk")
     p = params_of(g)
-    r, payload = _crafted_stream(p, lead_zeros)
+    r, payload = _crafted_stream(p, lead_zeros, lead_noise)
     ref = orc.receive(r, p)
     want_peaks = np.flatnonzero(ref["zeros"])
     assert len(want_peaks) == 7                                         # packets 0..5 + the terminating chirp: W1 is NOT among them
@@ -1160,8 +1164,10 @@ def test_receive_host_later_piece_changes_earlier_decisions(lead_zeros, list_cap
         # the provisional pass accepted W1, demodulated what followed it, and had to drop that at the end;
         # packet 0 was only found with the final maximum
         assert info["provisional_detections_dropped"] >= 1 and info["second_look_packets"] >= 1, info
+    elif lead_zeros == 50:
+        assert info["second_look_chunks"] >= 1, info                    # overflowing pieces that hold chirps: listed again
     else:
-        assert info["second_look_chunks"] >= 1, info
+        assert info.get("overflow_pieces_below_threshold", 0) >= 1 and info["second_look_chunks"] == 0, info   # a silent / noisy lead-in costs nothing
 
 
 def test_receive_host_fails_where_the_reference_fails():
