@@ -7,8 +7,9 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 spec = importlib.util.spec_from_file_location("gf3_config3", os.path.join(ROOT, "tools", "config3.py"))
 tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
+FRAMES = int(os.environ.get("GF3_H2D_FRAMES", "4096"))       # 28000: a 2.19 G-sample stream (lag indices past 2^31), 8.8 GB of f32
 eng, cfg, channel = tool.make_engine()
-r, payload = tool.make_stream(eng, channel, 4096)
+r, payload = tool.make_stream(eng, channel, FRAMES)
 host = torch.empty(r.numel(), dtype=r.dtype).pin_memory(); host.copy_(r); torch.cuda.synchronize()
 n = host.numel()
 dst = torch.empty_like(r)
@@ -26,5 +27,6 @@ for chunk in (1 << 24, 1 << 25, 1 << 26, 1 << 27):
     i = res["info"]
     print("receive_host chunk %10d: %.2f ms = %.1f GB/s, %.2f G samples/s, pieces %d (last call: setup %.2f, pieces %.2f, total %.2f ms)" % (
         chunk, t * 1e3, n * 4 / t / 1e9, n / t / 1e9, i["chunks"], i["setup_seconds"] * 1e3, i["pieces_seconds"] * 1e3, i["seconds"] * 1e3), flush=True)
-if os.environ.get("GF3_H2D_TRACE"):
-    print(json.dumps(res["info"]))
+one = eng.sync_stream(r)
+print("peaks equal the one-shot path:", bool(torch.equal(one, res["peaks"])), " bits equal:", bool(torch.equal(eng.demod_frames(r, (one + 2)[:-1])["bits"], res["bits"])),
+      " detections", int(one.numel()), res["info"])
