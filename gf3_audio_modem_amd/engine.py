@@ -390,7 +390,7 @@ class Engine:
         return llr
 
     # ------------------------------------------------------------------ host ingest (streams from host memory / longer than HBM)
-    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None):
+    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None, pin_in_place=True):
         """chirp sync + demodulation (the arithmetic of receiver.receive, OFDM.py:581-603) of a stream that lives in
         HOST memory, piece by piece: pinned, double-buffered H2D copies on a copy stream run under the kernels of the
         previous piece, and the result is that of the one-shot path -- the reference's rule with the GLOBAL maximum
@@ -404,8 +404,9 @@ class Engine:
         kill an earlier candidate, or un-suppressed one) are packets looked at again -- their samples re-read from the
         host array.  Pieces overlap by Lc + one packet, so no chirp and no packet is cut.
 
-        samples: 1-D numpy array or CPU torch tensor (a pinned tensor is copied from directly; anything else is staged
-        through pinned buffers, which costs a host memcpy per piece).  chunk_samples: new samples per piece (raised to
+        samples: 1-D numpy array or CPU torch tensor (a pinned tensor is copied from directly; pageable memory is pinned
+        in place for the duration of the call, or, if that is refused, staged through pinned buffers by a host copy per
+        piece).  chunk_samples: new samples per piece (raised to
         two packets if smaller).  Returns dict(peaks int64 [n_det] (device), bits uint8 [n_det - 1, bytes_per_frame]
         (device, packed), info).  Raises ValueError where the reference fails (fewer than two detections; a packet that
         runs past the end of the stream)."""
@@ -425,7 +426,26 @@ class Engine:
         n = x.numel()
         if n < 3:
             raise ValueError("stream too short")
-        pinned_in = x.is_pinned()
+        # Pageable input is PINNED IN PLACE for the duration of the call (hipHostRegister: 3 ms for 1.3 GB on the GPU box, after
+        # which the copies run at the pinned rate, 57 GB/s; staging every piece through a pinned buffer by a host copy runs at
+        # 4 GB/s on one thread).  Staging remains the fallback when the registration is refused.
+        registered = False
+        if pin_in_place and not x.is_pinned():
+            try:
+                registered = int(torch.cuda.cudart().cudaHostRegister(x.data_ptr(), n * x.element_size(), 0)) == 0
+            except Exception:
+                registered = False
+        try:
+            return self._receive_host(x, x.is_pinned() or registered, registered, chunk_samples, list_cap, t_start)
+        finally:
+            if registered:
+                torch.cuda.synchronize(self.device)
+                torch.cuda.cudart().cudaHostUnregister(x.data_ptr())
+
+    def _receive_host(self, x, pinned_in, registered, chunk_samples, list_cap, t_start):
+        import time
+        cfg = self.cfg
+        n = x.numel()
         Lc, L = cfg.chirp_length, cfg.M * cfg.S
         pieces, H, carry = host_pieces(n, chunk_samples, Lc, L)  # carry: samples of the previous piece kept in front of a piece
         nchunks = len(pieces)
@@ -459,7 +479,7 @@ class Engine:
         segs, overflow = [], []                                   # per piece: (first entry, entries) of the kept list; pieces whose list did not fit
         n_listed = 0
         BIG = (1 << 62)
-        info = dict(chunks=nchunks, chunk_samples=H, overlap_samples=carry, pinned_input=bool(pinned_in), h2d_bytes=0,
+        info = dict(chunks=nchunks, chunk_samples=H, overlap_samples=carry, pinned_input=bool(pinned_in), pinned_in_place=bool(registered), h2d_bytes=0,
                     second_look_chunks=0, second_look_packets=0, provisional_detections_dropped=0)
 
         def geometry(c):

@@ -1088,10 +1088,11 @@ def _config1_case():
     return g, p, F, r
 
 
-@pytest.mark.parametrize("storage", ["f64_pageable", "f32_pinned"])
+@pytest.mark.parametrize("storage", ["f64_pageable", "f64_staged", "f32_pinned"])
 def test_receive_host_chunked_equals_one_shot_and_reference(storage):
     """BASELINE config 1 (64 frames, the reference's own bits in the g1b fixture) from HOST memory in 33 pieces of
-    two packets each: peaks and bits of the one-shot device path and of the reference."""
+    two packets each -- pageable (pinned in place), pageable and staged, pinned -- : peaks and bits of the one-shot device
+    path and of the reference."""
     g, p, F, r = _config1_case()
     dt = torch.float64 if storage.startswith("f64") else torch.float32
     eng = engine_for(p, in_dtype=dt)
@@ -1100,9 +1101,10 @@ def test_receive_host_chunked_equals_one_shot_and_reference(storage):
         ref_bits = orc.receive(r.astype(np.float32).astype(np.float64), p)["bits"]
     else:
         host, ref_bits = r, unpack(g)
-    out = eng.receive_host(host, chunk_samples=1)                      # (raised to two packets per piece)
+    out = eng.receive_host(host, chunk_samples=1, pin_in_place=storage != "f64_staged")     # (raised to two packets per piece)
     info = out["info"]
-    assert info["chunks"] >= 4 and info["pinned_input"] == (storage == "f32_pinned"), info
+    # pageable memory is pinned in place for the call; "staged" forces the fallback (a host copy per piece into pinned buffers)
+    assert info["chunks"] >= 4 and info["pinned_input"] == (storage != "f64_staged") and info["pinned_in_place"] == (storage == "f64_pageable"), info
     x = torch.as_tensor(host).cuda()
     one = eng.sync_stream(x)
     assert torch.equal(out["peaks"], one) and out["peaks"].numel() == F + 1

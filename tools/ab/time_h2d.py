@@ -27,6 +27,14 @@ for chunk in (1 << 24, 1 << 25, 1 << 26, 1 << 27):
     i = res["info"]
     print("receive_host chunk %10d: %.2f ms = %.1f GB/s, %.2f G samples/s, pieces %d (last call: setup %.2f, pieces %.2f, total %.2f ms)" % (
         chunk, t * 1e3, n * 4 / t / 1e9, n / t / 1e9, i["chunks"], i["setup_seconds"] * 1e3, i["pieces_seconds"] * 1e3, i["seconds"] * 1e3), flush=True)
+if FRAMES <= 4096:                                          # pageable input: pinned in place for the call (staging through pinned buffers is the fallback)
+    pageable = host.numpy().copy()
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter(); res2 = eng.receive_host(pageable, chunk_samples=1 << 25); ts.append(time.perf_counter() - t)
+    t = float(np.median(ts[1:]))
+    print("receive_host from PAGEABLE memory (pinned in place: %s): %.2f ms = %.1f GB/s, %.2f G samples/s; peaks equal: %s" % (
+        res2["info"]["pinned_in_place"], t * 1e3, n * 4 / t / 1e9, n / t / 1e9, bool(torch.equal(res2["peaks"], res["peaks"]))), flush=True)
 one = eng.sync_stream(r)
 print("peaks equal the one-shot path:", bool(torch.equal(one, res["peaks"])), " bits equal:", bool(torch.equal(eng.demod_frames(r, (one + 2)[:-1])["bits"], res["bits"])),
       " detections", int(one.numel()), res["info"])
