@@ -53,6 +53,14 @@ def stream(name, buf, per_launch, wrap, blocks=2048, random_data=0):
 
 
 def main():
+    if os.environ.get("EB_STREAMS_ONLY"):
+        torch.cuda.init()
+        G = 1 << 30
+        _, idle = powered(lambda: time.sleep(SEC))
+        out = [spin("sleep", 512, 40960, 0, iters=2000)] + [stream(n, 16 * G, 16 * G, 0, random_data=r) for n, r in
+               (("hbm", 0), ("hbm_random", 1), ("hbm_8byte_loads", 2), ("hbm_random_8byte_loads", 3))]
+        print(json.dumps({"idle_w": idle, "points": out}, indent=1))
+        return
     torch.cuda.init()
     n_cu = torch.cuda.get_device_properties(0).multi_processor_count
     res = {"n_cu": n_cu, "seconds_per_point": SEC, "points": []}
@@ -79,6 +87,7 @@ def main():
         P.append(spin("fma64", cus, one, 0))
     G = 1 << 30
     res["streams"] = [stream("hbm", 16 * G, 16 * G, 0), stream("hbm_random", 16 * G, 16 * G, 0, random_data=1),
+                      stream("hbm_8byte_loads", 16 * G, 16 * G, 0, random_data=2), stream("hbm_random_8byte_loads", 16 * G, 16 * G, 0, random_data=3),
                       stream("infinity_cache", 128 << 20, 16 * G, 16 << 20), stream("l2", 8 << 20, 16 * G, 1 << 20),
                       stream("l2_random", 8 << 20, 16 * G, 1 << 20, random_data=1)]
     _, idle2 = powered(lambda: time.sleep(SEC))
