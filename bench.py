@@ -627,15 +627,24 @@ def main():
 
     # sustained package power: the same step repeated for ~2 s after the timed region (the hwmon sensor averages
     # over a window far longer than a 20-step run), median of the second half of the samples
-    power_w = None
+    power_w, sustained = None, None
     if not args.no_power:
         n_probe = int(2.0 / (dt / args.steps)) + 1            # dt is the max over ranks: the same count everywhere
         power = PowerSampler(local) if rank == 0 else None
         if power is not None:
             power.__enter__()
+        gd.barrier()
+        torch.cuda.synchronize()
+        t_probe = time.perf_counter()
         for _ in range(n_probe):                               # every rank steps (the N>1 step holds a collective)
             step()
         torch.cuda.synchronize()
+        gd.barrier()
+        t_probe = gd.max_over_ranks(time.perf_counter() - t_probe, dev)
+        # the same step over a window a hundred times longer than a 20-step timed region (same bracket: barrier +
+        # synchronize on both sides, maximum over ranks): a second reading of `value`, not a replacement for it
+        sustained = {"steps": n_probe, "seconds": t_probe, "ms_per_step": t_probe / n_probe * 1e3,
+                     "value": world * n_samples * n_probe / t_probe, "unit": "samples/s"}
         if power is not None:
             power.__exit__()
             if power.samples:
@@ -707,6 +716,7 @@ def main():
             "sync_exact": sync_ok,
             "gather_exact": gather_ok, "ranks_in_group": (torch.distributed.get_world_size() if multi else 1),
             "single_gather": single,
+            "sustained_2s": sustained,
             "collective": ({"backend": torch.distributed.get_backend(), "library_version": rccl_version(),
                             "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"),
                             "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))},
