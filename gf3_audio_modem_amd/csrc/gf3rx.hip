@@ -219,6 +219,9 @@ enum { MODE_FULL = 0, MODE_SCAN = 1, MODE_QPSK = 2 };
 #ifndef GF3_DEMOD_WPS
 #define GF3_DEMOD_WPS 2
 #endif
+#ifndef GF3_ABL
+#define GF3_ABL 0             /* timing-only ablations of the table modes (WRONG results): 1 no magnitude reads, 2 also ping-pong buffers */
+#endif
 // lean modes at GF3_DEMOD_WPS waves/SIMD; 3 needs the single in-place FFT buffer to fit 3 workgroups of LDS
 // MODE_QPSK keeps the two ping-pong FFT buffers.  The table modes carry two more doubles of state per carrier (the
 // magnitude model a0 + da f_l), which do not fit the register file next to the transform at two workgroups per CU;
@@ -227,7 +230,11 @@ enum { MODE_FULL = 0, MODE_SCAN = 1, MODE_QPSK = 2 };
 template <int NC, int MODE> struct DemodOcc {
     static constexpr int WPS = (MODE == MODE_QPSK && NC <= 2048) ? GF3_DEMOD_WPS : 2;
     static constexpr bool MAG_LDS = (MODE != MODE_QPSK);
+#if GF3_ABL >= 2
+    static constexpr bool PP = FftGeom<NC>::PINGPONG && WPS <= 2;
+#else
     static constexpr bool PP = FftGeom<NC>::PINGPONG && WPS <= 2 && !MAG_LDS;
+#endif
     static constexpr int LDS_ELEMS = PP ? FftGeom<NC>::LDS_ELEMS : FftGeom<NC>::LDS_ELEMS_INPLACE;
     static constexpr int MAG_ELEMS = MAG_LDS ? NC : 0;             // double2 (a0, da) per slot per thread: 8 * NC/8
 };
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     }
     if (tid == 0 && a.slope) a.slope[f] = slope;
     GF3_STAMP(3);
-    if constexpr (DemodOcc<NC, MODE>::MAG_LDS) {      // (block_sum's barriers: every thread is done with the fit-range arrays)
+    if constexpr (DemodOcc<NC, MODE>::MAG_LDS && GF3_ABL == 0) {      // (block_sum's barriers: every thread is done with the fit-range arrays)
 #pragma unroll
         for (int s = 0; s < 8; ++s) mags[s * T + tid] = make_double2(a0[s], da[s]);
     }
@@ -549,7 +556,11 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
                 const cplx ep = cmul_conj(v[s], g);                        // X / g  = e * mag
                 u[s] = cmul(g, gstep[s]);                                  // ... and for the next one
                 const int ps = pos_of(s);
+#if GF3_ABL >= 1
+                const double2 md = make_double2(1.0 + 1e-3 * s, 1e-4);
+#else
                 const double2 md = mags[s * T + tid];
+#endif
                 const double mag = fma(md.y, fl, md.x);
                 // bits only: the decision needs (ep / mag - lo) inv to far less than full precision (the margin of `clear`
                 // is 1e-9), so one Newton step serves and the quotient itself is never formed; the dumps of MODE_FULL
@@ -1892,7 +1903,7 @@ extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, cons
     } else if (c->qpsk_q > 0.0) {
         DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_QPSK>), F, NCC / 8, demod_lds_bytes(c, true), (hipStream_t)stream, a));
     } else {
-        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_SCAN>), F, NCC / 8, demod_lds_bytes(c), (hipStream_t)stream, a));
+        DISPATCH_NC(c->NC, g.in_dtype, e = launch((demod_kernel<NCC, DTC, false, MODE_SCAN>), F, NCC / 8, demod_lds_bytes(c, GF3_ABL >= 2), (hipStream_t)stream, a));
     }
     HIPCHK(c, e);
     return GF3_OK;
