@@ -618,6 +618,11 @@ class Engine:
         info["max"] = M
         return dict(peaks=torch.from_numpy(peaks).to(dev), bits=bits, info=info)
 
+    def release_host_buffers(self):
+        """Drop the calling thread's cached ingest resources (device buffers, workspace, pinned staging, copy stream):
+        receive_host keeps them between calls so that a receiver fed one recording after another does not allocate."""
+        self._tls.ingest = None
+
     # ------------------------------------------------------------------ bit helpers (layout only)
     def unpack_bits(self, packed):
         """[F, bytes_per_frame] uint8 -> [F * D*C*mu] uint8 0/1 (np.unpackbits order), on device."""
