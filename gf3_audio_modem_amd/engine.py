@@ -598,7 +598,7 @@ class Engine:
         for i in missing:
             if i + 2 + L > n:
                 raise ValueError("packet runs past the end of the stream")
-        info["provisional_detections_dropped"] = len(set(row_of) - set(det))
+        info["provisional_detections_dropped"] = len(set(row_of) - set(int(i) for i in peaks))   # (accepted with an earlier maximum, rejected by the final one)
         for k0 in range(0, len(missing), 64):                         # second look at single packets: samples re-read from the host
             grp = missing[k0: k0 + 64]
             seg = torch.stack([x[i + 2: i + 2 + L] for i in grp]).to(dev)
