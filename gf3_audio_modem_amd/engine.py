@@ -470,6 +470,9 @@ class Engine:
                        dwork=self._new((int(self.lib.gf3_sync_decide_workspace_bytes(self._h, cap_list)),), torch.uint8),
                        rows=self._new((cap_peaks, self.bytes_per_frame), torch.uint8))
             res["ev_copied"] = [torch.cuda.Event() for _ in res["bufs"]]
+            if not pinned_in:
+                from concurrent.futures import ThreadPoolExecutor
+                res["pool"] = ThreadPoolExecutor(4)
             self._tls.ingest = res
         copier, bufs, stage, ev_copied = res["copier"], res["bufs"], res["stage"], res["ev_copied"]
         idx_all, val_all, work, peaks_dev, dwork, rows = res["idx_all"], res["val_all"], res["work"], res["peaks_dev"], res["dwork"], res["rows"]
@@ -493,8 +496,13 @@ class Engine:
             src = x[lo_s:hi_s]
             if stage is not None:
                 ev_copied[b].synchronize()                        # the copy that last read this staging buffer is done
-                stage[b][: hi_s - lo_s].copy_(src)
-                src = stage[b][: hi_s - lo_s]
+                m, dst = hi_s - lo_s, stage[b]
+                if m >= (1 << 22):                                 # four host threads: 24 GB/s on the GPU box against 4 GB/s for one
+                    q = -(-m // 4)
+                    list(res["pool"].map(lambda k: dst[k * q: min(m, (k + 1) * q)].copy_(src[k * q: min(m, (k + 1) * q)]), range(4)))
+                else:
+                    dst[:m].copy_(src)
+                src = dst[:m]
             with torch.cuda.stream(copier):
                 bufs[b][carry: carry + (hi_s - lo_s)].copy_(src, non_blocking=True)
                 ev_copied[b].record(copier)
