@@ -2,6 +2,7 @@
 against fixtures written by tests/golden/make_golden.py from the unmodified
 reference, including the reference's own end-to-end known answer."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -198,3 +199,20 @@ def test_numpy_complex_abs_formula_restated_by_the_engine():
     assert np.array_equal(got, ref)
     hyp = np.array([math.hypot(z.real, z.imag) for z in d])                  # libm hypot (correctly rounded here)
     assert (hyp != ref).any()
+
+
+def test_bench_cpu_baseline_inputs_decode_to_their_payload():
+    """bench.py's CPU-baseline legs of configs 1 and 3 build their streams with the oracle's synthesiser: config 1 from the
+    seed the g1b fixture records (so its decoded bits are the reference's own), config 3 as a 24-packet slice through the
+    measured channel.  Both must decode, on the CPU, to what was sent (config 3: with the fixture's error floor)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gf3_bench_cpu", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r, pk, payload, _ = bench._config1_stream()
+    out = orc.receive(r, orc.RxParams(**pk))
+    g = load("g1b_config1_64f")
+    assert np.array_equal(out["bits"], payload) and np.array_equal(out["bits"], unpack(g))
+    r, pk, payload, _ = bench._config3_stream(F=4)
+    out = orc.receive(r, orc.RxParams(**pk))
+    assert len(out["starts"]) == 4 and np.mean(out["bits"] != payload) < 0.01
