@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Random geometries / storage / noise / thresholds through every stream-sync path against the oracle (the property
-test's generator with other seeds, more cases, lower thresholds and occasional interferers).  argv[1] = cases."""
+"""Random geometries / storage / noise / thresholds through every stream-sync path -- the screened call, the general
+screening kernel, the all-fp64 call, and the stream taken from host memory in pieces -- against the oracle (the property
+test's generator with other seeds, more cases, lower thresholds and occasional interferers).  argv[1] = cases, argv[2] = seed."""
 import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -41,6 +42,19 @@ for case in range(ncase):
         if not np.array_equal(got, want):
             bad += 1
             print("MISMATCH", case, dict(N=N, F=F, cp=cp, storage=storage, snr=snr, thresh=thresh, kind=int(kind), mode=mode), eng.sync_stream_info(), got[:6], want[:6], flush=True)
+    # ... and the stream taken from host memory in pieces of a random size (Engine.receive_host): same detections, or the
+    # reference's own failure (fewer than two detections; a non-last packet that runs past the end)
+    L = p.M * p.S
+    fails = len(want) < 2 or bool(np.any(want[:-1] + 2 + L > len(rq)))
+    try:
+        out = eng.receive_host(rq, chunk_samples=int(rs.uniform(2.0, 5.0) * p.frame_len))
+        ok = (not fails) and np.array_equal(out["peaks"].cpu().numpy(), want)
+        info = out["info"]
+    except ValueError as e:
+        ok, info = fails, str(e)
+    if not ok:
+        bad += 1
+        print("MISMATCH (host ingest)", case, dict(N=N, F=F, cp=cp, storage=storage, snr=snr, thresh=thresh, kind=int(kind)), info, want[:6], flush=True)
     eng.close()
     if case % 10 == 9: print("case", case + 1, "elapsed", round(time.time() - t0, 1), "mismatches", bad, flush=True)
 print("cases", ncase, "mismatches", bad)
