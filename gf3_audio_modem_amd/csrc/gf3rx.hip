@@ -1378,6 +1378,7 @@ struct gf3_ctx {
     double qpsk_q = 0.0;
     int* d_idx_of_label = nullptr;
     double* d_chirp = nullptr;
+    double* d_chirp_t = nullptr;  // the same taps in the order scr_refine_kernel's lanes consume them (RefineArgs::chirp_t)
     double* d_known_time = nullptr;     // one pilot symbol in the time domain (transmit side)
     SepTab sep{};
     UniGrid ug{};
@@ -1785,6 +1786,16 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
         for (int m = cfg->M - 1; m >= 0; --m) inv[clab[m]] = m;
         CK(upload(&c->d_idx_of_label, inv.data(), inv.size()));
         CK(upload(&c->d_chirp, c->chirp.data(), c->chirp.size()));
+        const int nst = (c->Lc + SCR_REF_WT - 1) / SCR_REF_WT;
+        std::vector<double> tiled((size_t)nst * SCR_REF_WT, 0.0);
+        for (int st = 0; st < nst; ++st)
+            for (int q = 0; q < 8; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = SCR_REF_WT * st + 16 * lane + 2 * q + h;
+                        if (k < c->Lc) tiled[(((size_t)st * 8 + q) * 64 + lane) * 2 + h] = c->chirp[k];
+                    }
+        CK(upload(&c->d_chirp_t, tiled.data(), tiled.size()));
         c->known_pts = known_pts;
     }
     CK(upload(&c->d_cre, cfg->const_re, (size_t)cfg->M));
@@ -1836,7 +1847,7 @@ extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
     if (!c) return;
     DeviceGuard dg(c);
     void* ptrs[] = {c->d_tw_x[0], c->d_twn_x[0], c->d_tw_x[1], c->d_twn_x[1], c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
-                    c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_known_time,
+                    c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_chirp_t, c->d_known_time,
                     c->scr.d_tw, c->scr.d_twn, c->scr.d_Hs, c->scr.d_H0N, c->scr.d_Hinf, c->scr.d_Hb, c->scr.d_ecoef};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete c;
@@ -2229,7 +2240,7 @@ static int sync_stream_screened(const gf3_ctx* c, const void* d_r, int64_t n, co
     hipLaunchKernelGGL(scr_scatter_kernel, dim3((unsigned)w.s_nwg), dim3(64), 0, st, (const unsigned long long*)segm, (const int64_t*)cnt,
                        (const int64_t*)offs, (const int64_t*)total, misc, cell, w.s_cap);
     {   // 3. their lags in fp64, once (the maximum is kept as the cells complete); the reference's rule on those values
-        RefineArgs a{d_r, n, dt, c->d_chirp, c->Lc, cell, misc, w.plen, cval};
+        RefineArgs a{d_r, n, dt, c->d_chirp, c->Lc, cell, misc, w.plen, cval, c->d_chirp_t, c->stamps};
         const int64_t slots = 2 * (int64_t)c->n_cu;                         // (the LDS staging allows two workgroups per CU)
         const int64_t wgs = (w.s_cap + 3) / 4;                               // (a wave per cell at a time)
         const unsigned grid = (unsigned)(wgs < slots ? wgs : slots);

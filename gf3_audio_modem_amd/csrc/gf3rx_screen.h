@@ -635,7 +635,6 @@ struct ScrMisc {                  // device-resident scalars of one gf3_sync_str
     long long ncell;              // cells listed (and re-evaluated)
     long long nhit;               // of those, cells that hold a candidate
     long long status;             // bit 0: the work list overflowed -> the caller falls back to the all-fp64 path
-    unsigned long long next;      // work counter of scr_refine_kernel
     unsigned long long mlo_key;   // running maximum of (blk_max - blk_err) as an ordered key (0: none yet)
     unsigned long long m_key;     // running maximum of the fp64 values, same encoding
     unsigned int mlo_done;        // workgroups of scr_mlo_kernel that have contributed
@@ -797,140 +796,230 @@ __global__ __launch_bounds__(64) void scr_scatter_kernel(const unsigned long lon
 // fp64 re-evaluation of the 16 lags of one cell: P[m] = sum_k r[m - Lc + 1 + k] c[k], m = 14 c + j, j = 0..15.
 // Each thread takes a contiguous range of taps and slides a 31-sample window over them, 16 taps at a time
 // (256 fma per 31 sample loads + 16 tap loads); the 16 partial sums are then reduced over the workgroup.
+template <int DT> struct ScrStage { typedef float S; };      // what scr_refine_kernel stages a sample as
+template <> struct ScrStage<DT_F64> { typedef double S; };
 struct RefineArgs {
     const void* in; int64_t n_in; int dt;
     const double* chirp; int Lc;
     const int64_t* cells; ScrMisc* misc;
     int64_t plen;
     double* cell_val;             // [ncell][16] the cell's fp64 lags (their maximum goes to misc->m_key / m_nan)
+    const double* chirp_t;        // the taps tiled for scr_refine_kernel: [step][q < 8][lane][2] = c[1024 step + 16 lane + 2 q + (0, 1)], 0 past Lc
+    unsigned long long* stamps;   // diagnostic build only (-DGF3_STAMPS): [waves][8] s_memtime ticks summed per phase (tools/ab/refine_stamps.py)
 };
+#ifdef GF3_STAMPS
+// s_memtime once everything the wave has in flight on the scalar / LDS side has returned; nothing is scheduled across it
+#define SCR_TICK(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); \
+                         __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SCR_TICK(t) do { } while (0)
+#endif
 #define SCR_REF_THREADS 256
-#define SCR_REF_WT 1024                              /* taps staged per wave and step: 16 per lane */
-// Every WAVE works on its own: it draws a cell from the counter, walks the cell's taps 1024 at a time and owns a
-// private slice of LDS for the staging, so there is no workgroup barrier anywhere and the 8 waves of a CU drift apart
-// -- one wave's LDS phase runs under another's fma phase (with workgroup-wide steps and two barriers per step the
-// phases of all waves lined up and the kernel ran at 20 % of the fp64 rate).
-// Staging keeps the global loads coalesced (a lane's own 31 samples are 124 bytes of a line nobody else in the wave
-// touches at that moment): samples and taps go to LDS as doubles, element e at e + (e >> 4) -- a lane then reads its 16
-// taps and 31 samples at a stride of 17 doubles, which is conflict-free.  The raw samples and taps of the next step
-// (the next cell's first step included: its number is drawn while the current cell is being computed) are fetched
-// into registers while the current step runs out of LDS; no load depends on another load of the same step.
+#define SCR_REF_WT 1024                              /* taps per wave and step: 16 per lane */
+// Every WAVE works on its own: it walks its cells' taps 1024 at a time and owns a private slice of LDS for the samples, so
+// there is no workgroup barrier anywhere.  What the first version of this kernel (rounds 1-2: samples AND taps staged
+// through LDS as doubles, 57 LDS instructions per step; cells drawn from a work counter) was bound by was measured in
+// round 3 with s_memtime stamps per phase, timing-only ablations and SQ_LDS_* counters: neither
+// the LDS array nor the HBM latency, but (i) the NUMBER of LDS and vector-memory instructions a wave has to get through
+// beside its 256 fma per step -- at two waves per SIMD an LDS instruction of any width costs a wave ~30 cycles -- and
+// (ii) two atomic additions per wave on one address at the start of the kernel: 4 096 of them, served one after the
+// other, were 40 of its 210 us.  This version
+//   * stages the samples RAW (4 bytes each; 8 for an f64 stream): a lane loads 16 consecutive bytes of the stream
+//     (coalesced, 1 KB per wave-instruction), stores them with one ds_write_b128 and reads its own 31-sample window back
+//     with 8 ds_read_b128 (16 for f64), widening to double in registers.  A lane's 16 elements are followed by one
+//     16-byte pad, so a lane's run is 80 (144) bytes: runs stay 16-byte aligned and the reads are conflict-free under
+//     the b128 lane groups;
+//   * keeps the taps out of LDS: they are the same for every cell, so the context holds them tiled the way the lanes
+//     consume them (RefineArgs::chirp_t) and a lane's 16 taps of a step are 8 coalesced 16-byte loads into registers;
+//   * deals the cells to the waves by a fixed stride (every cell costs the same) and keeps everything about a wave's
+//     position in scalar registers, a cell's number fetched by a scalar load;
+//   * reduces the 16 partial sums over the wave by halving: each level exchanges only the half a lane does not keep
+//     (8 + 4 + 2 + 1 + 1 + 1 = 17 exchanges instead of 96).  The pairing of every addition is that of the butterfly it
+//     replaces and the order of a lane's own fma is unchanged, so the values are bit-for-bit those of the first version.
+// 13 (25) LDS instructions per step instead of 57, 42 per cell's reduction instead of 192; 211 -> 150 us on the config-3
+// stream (5 267 cells), of which ~35 us are the 13 KB a wave pulls through the vector-memory pipe per step.
 template <int DT>
 __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineArgs a) {
     constexpr int WT = SCR_REF_WT, NW = SCR_REF_THREADS / 64;
-    __shared__ double xs_all[NW][WT + 16 + (WT + 16) / 16 + 1];
-    __shared__ double cs_all[NW][WT + WT / 16];
     typedef typename RawT<DT>::E E;
+    typedef typename ScrStage<DT>::S S;                                   // what LDS holds (exact for every sample type)
+    constexpr int PER = 16 / (int)sizeof(S);                              // elements per 16-byte access: 4 (2)
+    constexpr int GPR = 16 / PER;                                         // 16-byte groups per lane run: 4 (8)
+    constexpr int NG = (WT + 16) / PER;                                   // groups staged per step: 260 (520)
+    constexpr int NQ = (NG + 63) / 64;                                    // stores per lane and step: 5 (9)
+    constexpr int NR = (31 + PER - 1) / PER;                              // reads per lane and step: 8 (16)
+    typedef S SV __attribute__((ext_vector_type(PER)));
+    typedef double D2 __attribute__((ext_vector_type(2)));
+    struct __attribute__((packed, aligned(sizeof(E)))) RawV { E v[PER]; };  // PER consecutive samples, aligned like one
+    constexpr int SPARE = (WT + 16) / 16 * (GPR + 1);                    // 64 slots behind the runs for the lanes the last store has no group for
+    __shared__ SV xs_all[NW][SPARE + 64];
     if (a.misc->status & 1) return;
-    const long long ncell = a.misc->ncell;
+    const int ncell = __builtin_amdgcn_readfirstlane((int)a.misc->ncell);   // (<= the capacity of the list, far below 2^31)
     const int lane = threadIdx.x & 63;
-    double* xs = xs_all[threadIdx.x >> 6];
-    double* cs = cs_all[threadIdx.x >> 6];
+    SV* xs = xs_all[threadIdx.x >> 6];
     const int nst = (a.Lc + WT - 1) / WT;             // steps per cell
-    const int look = nst > 1 ? 1 : 0;                 // the step at which the next cell's number is looked up
-    auto first_lane64 = [](unsigned long long v) -> long long {
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-        return (long long)(((unsigned long long)hi << 32) | lo);
+    // A wave's work is a stream of items (cell, step); three of them are in flight: `c` is being computed out of LDS,
+    // `w` has its samples in registers and its taps on the way, `f` is being fetched.  All three are wave-uniform.
+    // The cells are dealt to the waves by a fixed stride -- every cell costs the same.  (Drawing them from a counter, as
+    // the first version did, opens the kernel with two atomic additions per wave on one address: 4 096 of them, served
+    // one after the other, were 40 of the kernel's 190 us.)  With two workgroups per CU the stride also leaves the
+    // cells of the last, partial round to the first workgroup of every CU, one wave per SIMD.
+    // Everything about an item lives in scalar registers, and a cell's number is fetched with a scalar load: as a vector
+    // load it made the compiler wait for ALL the wave's vector loads (vmcnt(0)) -- the prefetches of the next steps -- at
+    // every step.
+    struct Item { int cur; int64_t cell; int st; };
+    const int nwaves = (int)gridDim.x * NW;
+    auto cell_at = [&](int i) -> int64_t {             // a.cells[i], i wave-uniform
+        long long v;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(a.cells + i) : "memory");
+        return v;
     };
-    unsigned long long drawn = 0;
-    if (lane == 0) drawn = atomicAdd((unsigned long long*)&a.misc->next, 1ull);
-    long long cur = first_lane64(drawn);
-    if (cur >= ncell) return;                          // (per wave: nothing below synchronises across waves)
-    int64_t cur_cell = a.cells[cur];
-    E xr[17];
-    double cr[16];
-    auto fetch = [&](int64_t c, int st) {
-        const int k0 = st * WT;
-        const int64_t i0 = GF3_SCR_CELL * c - (a.Lc - 1) + k0;
-        if (i0 >= 0 && i0 + WT + 15 <= a.n_in) {        // (uniform) the whole step lies inside the stream
-            const E* base = (const E*)a.in + i0 + lane;     // (one address per lane, the rest are immediate offsets)
+    auto advance = [&](const Item& it) -> Item {       // the item after `it` (it.cur < ncell)
+        if (it.st + 1 < nst) return Item{it.cur, it.cell, it.st + 1};
+        const int nc = it.cur + nwaves;
+        return Item{nc, nc < ncell ? cell_at(nc) : 0, 0};
+    };
+    RawV xr[NQ];
+    D2 tn[8];
+    const unsigned lane16 = 16u * lane;                // (a wave-uniform base plus this: the scalar-base form of global_load)
+    auto fetch = [&](const Item& it) {                 // the item's samples -> xr
+        const int64_t i0 = GF3_SCR_CELL * it.cell - (a.Lc - 1) + (int64_t)it.st * WT;
+        if (i0 >= 0 && i0 + WT + 16 <= a.n_in) {        // (uniform) the whole step lies inside the stream
+            const E* base = (const E*)a.in + i0 + PER * lane;   // (one address per lane, the rest are immediate offsets)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) xr[q] = base[64 * q];
-            const int l15 = launder(lane);                  // (recomputed per step: hoisted, its 64-bit form is spilled for 1-byte samples)
-            xr[16] = ((const E*)a.in + i0)[WT + (l15 < 15 ? l15 : 14)];
+            for (int q = 0; q < NQ - 1; ++q) xr[q] = *(const RawV*)(base + 64 * PER * q);
+            const int lt = launder(lane);
+            xr[NQ - 1] = *(const RawV*)((const E*)a.in + i0 + PER * (64 * (NQ - 1) + (lt < NG - 64 * (NQ - 1) ? lt : 0)));
         } else {
             const int64_t last_i = a.n_in - 1;
 #pragma unroll
-            for (int q = 0; q < 17; ++q) {
-                const int64_t i = i0 + lane + 64 * q;
-                const int64_t ic = i < 0 ? 0 : (i > last_i ? last_i : i);
-                const E val = ((const E*)a.in)[ic];
-                xr[q] = (i == ic) ? val : (E)0;
-            }
-        }
-        if (k0 + WT <= a.Lc) {                          // (uniform)
-            const double* cl = a.chirp + k0 + lane;
+            for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) cr[q] = cl[64 * q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int k = k0 + lane + 64 * q;
-                const double val = a.chirp[k < a.Lc ? k : a.Lc - 1];
-                cr[q] = k < a.Lc ? val : 0.0;
+                for (int t = 0; t < PER; ++t) {
+                    const int64_t i = i0 + PER * (lane + 64 * q) + t;
+                    const int64_t ic = i < 0 ? 0 : (i > last_i ? last_i : i);
+                    const E val = ((const E*)a.in)[ic];
+                    xr[q].v[t] = (i == ic) ? val : (E)0;
+                }
             }
         }
     };
-    fetch(cur_cell, 0);
+    auto fetch_taps = [&](int st) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) tn[q] = *(const D2*)((const char*)a.chirp_t + (size_t)st * (8 * 1024) + lane16 + 1024 * q);
+    };
+    auto stage = [&]() {                               // xr -> this wave's LDS (LDS serves a wave's instructions in order:
+#pragma unroll                                         //  the reads of the step before were issued ahead of these stores)
+        for (int q = 0; q < NQ; ++q) {
+            const int g = lane + 64 * q;
+            SV v;
+#pragma unroll
+            for (int t = 0; t < PER; ++t) v[t] = (S)xr[q].v[t];
+            xs[(q < NQ - 1 || g < NG) ? g + g / GPR : SPARE + lane] = v;   // (a store by every lane: no branch in the step)
+        }
+    };
+    Item c, w, f;
+    {
+        const int first = (int)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (first >= ncell) return;                    // (per wave: nothing below synchronises across waves)
+        c = Item{first, cell_at(first), 0};
+        fetch(c); fetch_taps(0);
+        w = advance(c);
+        stage();
+        if (w.cur < ncell) fetch(w);
+        f = w.cur < ncell ? advance(w) : w;
+    }
     double acc[16];
-    long long pending = 0;                             // the item after `cur` ...
-    int64_t pending_cell = 0;                          // ... and its cell number
-    int st = 0;
+#ifdef GF3_STAMPS
+    unsigned long long tk0 = 0, tk3 = 0, tk4 = 0, t_first = 0, s_body = 0, s_tail = 0, s_next = 0, n_steps = 0;
+    SCR_TICK(t_first);
+    unsigned long long rt0, rt1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) :: "memory");
+#endif
     while (true) {
-        if (st == 0) {
+#ifdef GF3_STAMPS
+        SCR_TICK(tk0);
+#endif
+        if (c.st == 0) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = 0.0;
-            drawn = 0;
-            if (lane == 0) drawn = atomicAdd((unsigned long long*)&a.misc->next, 1ull);
         }
-        if (st == look) {                              // (one step after the draw: the counter's answer is back by now, and
-            pending = first_lane64(drawn);             //  the cell number has the rest of the cell's steps to arrive)
-            pending_cell = pending < ncell ? a.cells[pending] : 0;
+        // this step's window out of LDS, its taps out of the prefetch registers; then the next item's samples to LDS, its
+        // taps and the samples of the item after it requested -- none of that is waited for in this step.  (Spreading these
+        // 5 stores and 13 loads over the fma with sched_group_barrier, as one basic block, changed nothing: 150.9 vs 151.7 us.)
+        double x[NR * PER];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const SV v = xs[(GPR + 1) * lane + r + r / GPR];
+#pragma unroll
+            for (int t = 0; t < PER; ++t) x[PER * r + t] = (double)v[t];
         }
-        // registers -> this wave's LDS (its reads of the previous step were issued before these writes: LDS serves a
-        // wave's instructions in order)
+        D2 tc[8];
 #pragma unroll
-        for (int q = 0; q < 17; ++q) { const int e = lane + 64 * q; if (q < 16 || lane < 15) xs[e + (e >> 4)] = (double)xr[q]; }
+        for (int q = 0; q < 8; ++q) tc[q] = tn[q];
+        if (w.cur < ncell) { stage(); fetch_taps(w.st); }
+        if (f.cur < ncell) fetch(f);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { const int e = lane + 64 * q; cs[e + (e >> 4)] = cr[q]; }
-        asm volatile("" ::: "memory");
-        const bool last = (st == nst - 1);
-        const long long nx = last ? pending : cur;
-        const int64_t nx_cell = last ? pending_cell : cur_cell;
-        if (nx < ncell) fetch(nx_cell, last ? 0 : st + 1);
-        {
-            double x[31];
+        for (int kk = 0; kk < 16; ++kk) {
+            const double ck = tc[kk >> 1][kk & 1];
 #pragma unroll
-            for (int i = 0; i < 31; ++i) x[i] = xs[17 * lane + i + (i >> 4)];
+            for (int j = 0; j < 16; ++j) acc[j] = fma(ck, x[kk + j], acc[j]);
+        }
+#ifdef GF3_STAMPS
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const double ck = cs[17 * lane + kk];
+        for (int j = 0; j < 16; ++j) asm volatile("" : "+v"(acc[j]));
+        SCR_TICK(tk3);
+#endif
+        if (c.st == nst - 1) {
+            // ---- the cell is complete: sum the 16 partial sums over the wave.  Level d leaves a lane with the half of its
+            // values selected by its bit d and adds the partner's copy of that half; after d = 32, 16, 8, 4 a lane holds
+            // the one sum j = (lane >> 2) & 15, which d = 2, 1 complete.
+            const int64_t m0 = GF3_SCR_CELL * c.cell;
+            double s;
+            {
+                double v8[8], v4[4], v2[2];
+                const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc[j] = fma(ck, x[kk + j], acc[j]);
+                for (int t = 0; t < 8; ++t) { const double give = b5 ? acc[t] : acc[t + 8], keep = b5 ? acc[t + 8] : acc[t]; v8[t] = keep + __shfl_xor(give, 32, 64); }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { const double give = b4 ? v8[t] : v8[t + 4], keep = b4 ? v8[t + 4] : v8[t]; v4[t] = keep + __shfl_xor(give, 16, 64); }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) { const double give = b3 ? v4[t] : v4[t + 2], keep = b3 ? v4[t + 2] : v4[t]; v2[t] = keep + __shfl_xor(give, 8, 64); }
+                { const double give = b2 ? v2[0] : v2[1], keep = b2 ? v2[1] : v2[0]; s = keep + __shfl_xor(give, 4, 64); }
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 1, 64);
+            }
+            const int j = (lane >> 2) & 15;
+            const bool counts = m0 + j < a.plen;
+            if ((lane & 3) == 0) a.cell_val[(int64_t)c.cur * 16 + j] = s;
+            const bool nan = __ballot(counts && !(s == s)) != 0ull;
+            double mx = (counts && s == s) ? s : -INFINITY;
+#pragma unroll
+            for (int d = 32; d >= 4; d >>= 1) mx = fmax(mx, __shfl_xor(mx, d, 64));
+            if (lane == 0) {
+                if (nan) atomicOr(&a.misc->m_nan, 1u);
+                else if (mx > -INFINITY) atomicMax(&a.misc->m_key, scr_key(mx));
             }
         }
-        asm volatile("" ::: "memory");
-        if (!last) { ++st; continue; }
-        // ---- the cell is complete: sum the 16 partial sums over the wave, keep them
-        const int64_t m0 = GF3_SCR_CELL * cur_cell;
-        double mine = 0.0, mx = -INFINITY;
-        bool nan = false;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            double s = acc[j];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-            mine = (lane == j) ? s : mine;
-            if (m0 + j < a.plen) { mx = fmax(mx, s); nan = nan || !(s == s); }
-        }
-        if (lane < 16) a.cell_val[cur * 16 + lane] = mine;
-        if (lane == 0) {
-            if (nan) atomicOr(&a.misc->m_nan, 1u);
-            else if (mx > -INFINITY) atomicMax(&a.misc->m_key, scr_key(mx));
-        }
-        if (nx >= ncell) break;                        // (uniform)
-        cur = nx; cur_cell = nx_cell; st = 0;
+#ifdef GF3_STAMPS
+        SCR_TICK(tk4);
+        s_body += tk3 - tk0; s_tail += tk4 - tk3; ++n_steps;
+#endif
+        if (w.cur >= ncell) break;                     // (uniform)
+        c = w; w = f;
+        if (f.cur < ncell) f = advance(f);
+#ifdef GF3_STAMPS
+        SCR_TICK(tk0);
+        s_next += tk0 - tk4;
+#endif
     }
+#ifdef GF3_STAMPS
+    if (a.stamps && lane == 0) {
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 8;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");
+        o[0] = tk4 - t_first; o[1] = rt0; o[2] = rt1; o[3] = s_body; o[4] = s_tail; o[5] = s_next; o[6] = 0; o[7] = n_steps;
+    }
+#endif
 }
 
 // The same re-evaluation on the fp64 matrix cores.  With taps k = 16 a + b and s = j + b, the 16 lags of a cell are the
@@ -942,6 +1031,7 @@ __global__ __launch_bounds__(SCR_REF_THREADS, 2) void scr_refine_kernel(RefineAr
 #ifndef GF3_REFINE_MFMA
 #define GF3_REFINE_MFMA 0
 #endif
+
 typedef double scr_d4 __attribute__((ext_vector_type(4)));
 template <int DT>
 __global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_mfma_kernel(RefineArgs a) {
