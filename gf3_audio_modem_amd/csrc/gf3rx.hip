@@ -1404,6 +1404,15 @@ struct gf3_ctx {
 static thread_local char g_err[512] = "";
 // ... and the diagnostics of the calling thread's last gf3_sync_stream / gf3_sync_stream_ex (gf3_sync_stream_info)
 static thread_local int64_t g_last_info[4] = {0, 0, 0, 0};
+// Where a call reads its few result words back to: 256 bytes of PINNED host memory per calling thread (allocated on the
+// thread's first call, never freed: a copy into pageable memory goes through the runtime's staging path, which costs a call
+// tens of microseconds).  nullptr if the allocation fails -- the caller then copies into a local variable as before.
+static void* readback_buffer() {
+    static thread_local void* p = nullptr;
+    static thread_local bool tried = false;
+    if (!tried) { tried = true; if (hipHostMalloc(&p, 256, hipHostMallocPortable) != hipSuccess) { p = nullptr; (void)hipGetLastError(); } }
+    return p;
+}
 
 // Scratch device allocations of the set-up helpers: released on every return path.
 struct DevTmp {
@@ -2321,7 +2330,10 @@ extern "C" int gf3_sync_stream_ex(const gf3_ctx* c, const void* d_r, int64_t n, 
     if (!d_corr && c->scr.ok && w.s_nblk > 0 && (mode >= 2 || (mode == 0 && n >= GF3_SCR_MIN_SAMPLES))) {
         int rc = sync_stream_screened(c, d_r, n, w, base, d_peaks, cap, mode, st);
         if (rc != GF3_OK) return rc;
-        ScrMisc hm;
+        static_assert(sizeof(ScrMisc) <= 256, "readback_buffer() holds 256 bytes");
+        ScrMisc hm_local;
+        void* pin = readback_buffer();
+        ScrMisc& hm = pin ? *(ScrMisc*)pin : hm_local;
         HIPCHK(c, hipMemcpyAsync(&hm, base + w.o_smisc, sizeof(ScrMisc), hipMemcpyDeviceToHost, st));      // (the one read-back of the call)
         HIPCHK(c, hipStreamSynchronize(st));
         const int64_t h[2] = {hm.np[0], hm.np[1]}, ncand = hm.total;
@@ -2365,7 +2377,8 @@ extern "C" int gf3_sync_stream_ex(const gf3_ctx* c, const void* d_r, int64_t n, 
     hipLaunchKernelGGL(pk_nms, dim3(1), dim3(NMS_THREADS), 0, st, (const int64_t*)cand, (const int64_t*)total,
                        (int64_t)c->Lc, w.nz, d_peaks, cap, np);
     HIPCHK(c, hipGetLastError());
-    int64_t h[2] = {0, 0};
+    int64_t h_local[2] = {0, 0};
+    int64_t* h = readback_buffer() ? (int64_t*)readback_buffer() : h_local;
     HIPCHK(c, hipMemcpyAsync(h, np, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     *n_peaks = h[0];
@@ -2535,8 +2548,11 @@ extern "C" int gf3_sync_chunk(const gf3_ctx* c, const void* d_buf, int64_t n, in
                        c->cfg.thresh, lag_offset, cnt, (const int64_t*)nullptr, (int64_t*)nullptr, (double*)nullptr);
     hipLaunchKernelGGL(pk_scan, dim3(1), dim3(1024), 0, st, (const int64_t*)cnt, nb, offs, total, (const long long*)nullptr, (const long long*)nullptr);
     HIPCHK(c, hipGetLastError());
-    int64_t want = 0;
-    double pmax = -INFINITY;
+    int64_t want_local = 0;
+    double pmax_local = -INFINITY;
+    void* pin = readback_buffer();
+    int64_t& want = pin ? *(int64_t*)pin : want_local;
+    double& pmax = pin ? *(double*)((char*)pin + 8) : pmax_local;
     HIPCHK(c, hipMemcpyAsync(&want, total, 8, hipMemcpyDeviceToHost, st));
     if (h_piece_max) HIPCHK(c, hipMemcpyAsync(&pmax, d_run_max + 1, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -2569,7 +2585,8 @@ extern "C" int gf3_sync_decide(const gf3_ctx* c, const int64_t* d_idx, const dou
     hipLaunchKernelGGL(pk_nms, dim3(1), dim3(NMS_THREADS), 0, st, (const int64_t*)cand, (const int64_t*)total,
                        (int64_t)c->Lc, nz_total, d_peaks, cap, np);
     HIPCHK(c, hipGetLastError());
-    int64_t h[2] = {0, 0};
+    int64_t h_local[2] = {0, 0};
+    int64_t* h = readback_buffer() ? (int64_t*)readback_buffer() : h_local;
     HIPCHK(c, hipMemcpyAsync(h, np, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     *n_peaks = h[0];
