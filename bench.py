@@ -259,6 +259,57 @@ def cpu_baseline_streams(pool, cores, target_s=4.0):
     return out
 
 
+def final_system_test_leg(reps=20, warm=3, cpu=True):
+    """The reference's own end-to-end case -- `Final System Test.ipynb` cells 5-8: the 8-bit over-the-air recording
+    gr5ch1_signal.wav through receiver(mode="A2").receive() -- through the drop-in class, HOST array in, decoded bits on
+    the host out (upload, chirp sync with the reference's rule, 3 packets x (20 + 180 + 20) symbols, XOR decode, copies
+    back; wall clock, median of `reps` calls after `warm`).  The recording travels as a test fixture (tests/golden)."""
+    import contextlib, hashlib, io
+    path = os.path.join(ROOT, "tests", "golden", "g6_realrec.npz")
+    if not os.path.exists(path):
+        return {}
+    g = np.load(path)
+    wav = g["wav_u8"]
+    from gf3_audio_modem_amd.OFDM import receiver
+    times = []
+    with contextlib.redirect_stdout(io.StringIO()):                  # (the class prints the reference's banners)
+        rx = receiver(mode="A2", encoding="XOR")
+        for i in range(warm + reps):
+            t = time.perf_counter()
+            bits, _, _ = rx.receive(wav)
+            dt = time.perf_counter() - t
+            if i >= warm:
+                times.append(dt)
+    med = float(np.median(times))
+    src = np.unpackbits(g["src_bits"])[: int(g["n_src"])]
+    ber = float(np.sum(bits[: len(src)] != src) / len(src))
+    out = {"workload": f"Final System Test.ipynb: gr5ch1_signal.wav ({len(wav)} samples, 8-bit PCM, 48 kHz, over the air), mode A2 "
+                       f"(N=4096, CP=224, bins 100-1499, QPSK, XOR), receiver.receive() from a host array to bits on the host",
+           "ms_per_call": med * 1e3, "samples_per_s": len(wav) / med, "timing": f"wall clock, median of {reps} calls after {warm}",
+           "bits": int(len(bits)), "bits_sha256_equal_reference": hashlib.sha256(bits.astype(np.uint8).tobytes()).hexdigest() == str(g["sha256_bits"]),
+           "ber_vs_source": repr(ber), "ber_string_equal_reference": repr(ber) == str(g["ber_str"]),
+           "reference_as_written_s": 20.3, "reference_note": "OFDM.py unmodified, 1 thread, measured in the build container (BASELINE.md section 2), not on this host"}
+    if cpu:
+        from oracle import gf3_oracle as orc                         # the CPU baseline of this leg: the restatement on this host
+        try:
+            from threadpoolctl import threadpool_limits
+        except Exception:
+            threadpool_limits = None
+        pts, bt = orc.qpsk_table()
+        p = orc.RxParams(N=4096, CP=224, P=20, D=180, lo=100, hi=1500, const_points=pts, const_bits=bt, known_bits=g["known_bits"])
+        ctx = threadpool_limits(limits=1) if threadpool_limits else None
+        try:
+            r64 = wav / 1.0
+            orc.xor_decode(orc.receive(r64, p)["bits"], p)                                    # (warm-up)
+            t = time.perf_counter(); cb = orc.xor_decode(orc.receive(r64, p)["bits"], p); dt = time.perf_counter() - t
+        finally:
+            if ctx is not None and hasattr(ctx, "unregister"):
+                ctx.unregister()
+        out["cpu_baseline"] = {"value": len(wav) / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+                               "sample": f"the whole recording through oracle.receive + xor_decode once, {dt:.3f} s; bits equal the GPU's: {bool(np.array_equal(cb, bits))}"}
+    return {"final_system_test": out}
+
+
 def _event_ms(fn, reps=20, warm=3):
     """SURVEY 8(d) protocol for the secondary legs: MEDIAN HIP-event time of `fn` (one launch on the current stream)
     over `reps` >= 20 launches after `warm` = 3 untimed ones, in ms"""
@@ -481,6 +532,7 @@ def main():
                          "through a one-rank RCCL group; a rehearsal of the multi-GPU path, not the headline number")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 rFFT / soft-demap roofline legs (N=1)")
     ap.add_argument("--no-stream", action="store_true", help="skip the config-3 stream-sync roofline leg (N=1)")
+    ap.add_argument("--no-final-system-test", action="store_true", help="skip the leg that runs the reference's own recording through the drop-in class (N=1)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-ingest (pinned, chunked H2D + stream receive) leg (N=1)")
     ap.add_argument("--gather-algo", default=None, help="N>1: NCCL_ALGO for the all-gather (e.g. Ring, Tree, Direct), set before the "
                     "process group exists, so that a scaling run can compare algorithms (SURVEY section 5) without a code change")
@@ -688,6 +740,8 @@ def main():
             extra.update(config5_rooflines(dev))
         if not args.no_stream:
             extra.update(stream_sync_roofline(dev, pmc=pmc, h2d=not args.no_h2d))
+        if not args.no_final_system_test:
+            extra.update(final_system_test_leg(cpu=not args.no_cpu))
         extra["hbm_copy_measured"] = measured_copy_bandwidth(dev)
 
     if rank == 0:

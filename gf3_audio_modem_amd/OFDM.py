@@ -343,6 +343,22 @@ class receiver(transmitter):
             return torch.bitwise_xor(b, k).cpu().numpy()
         return bits_encoded
 
+    def _decode_device(self, bits_u8):
+        """decode() for receive(): the 0/1 decisions are still on the device, so the XOR runs there and the int64 array the
+        reference returns crosses PCIe once, into pinned memory that becomes the numpy array (decode() itself, handed a host
+        array, has to upload it first)."""
+        if self.encoding == "LDPC":
+            raise NotImplementedError("LDPC decoding is out of scope (pyldpc; marked broken in the reference, OFDM.py:21)")
+        b = bits_u8.to(torch.int64)
+        if self.encoding == "XOR":
+            n = b.numel()
+            known = torch.as_tensor(np.asarray(self.known_sequence[: self.data_bits_per_symbol], dtype=np.int64)).to(b.device)
+            b = torch.bitwise_xor(b, known.repeat(-(-n // len(known)))[:n])
+        out = torch.empty(b.numel(), dtype=torch.int64, pin_memory=True)
+        out.copy_(b, non_blocking=True)
+        torch.cuda.current_stream(b.device).synchronize()
+        return out.numpy()
+
     # ---- whole receive chain (OFDM.py:581-657) ----------------------------------------
     def receive(self, signal, graph_output=False):
         print("-" * 42 + "\nReceive \n" + "-" * 42)
@@ -369,9 +385,8 @@ class receiver(transmitter):
         print("Number of received OFDM symbols:    " + str(self.no_packets * self.packet_length))
         want = ("Hs", "He", "slope") + (("Hest", "eq") if graph_output else ())
         o = eng.demod_frames(x, starts, want=want)
-        bits = eng.unpack_bits(o["bits"]).to(torch.int64).cpu().numpy()
+        bits = self._decode_device(eng.unpack_bits(o["bits"]))
         self._last_slope = o["slope"].cpu().numpy()
-        bits = self.decode(bits)
         print("Number of received bits:            " + str(len(bits)))
         Hest_start, Hest_end = o["Hs"].cpu().numpy(), o["He"].cpu().numpy()
         if graph_output:
@@ -388,7 +403,7 @@ class receiver(transmitter):
         starts = (res["peaks"] + 2)[:-1]
         self.no_packets = int(starts.numel())
         print("Number of received OFDM symbols:    " + str(self.no_packets * self.packet_length))
-        bits = self.decode(eng.unpack_bits(res["bits"]).to(torch.int64).cpu().numpy())
+        bits = self._decode_device(eng.unpack_bits(res["bits"]))
         print("Number of received bits:            " + str(len(bits)))
         L = (2 * self.no_pilots + self.packet_length) * (self.cp_length + self.ofdm_symbol_size)
         s0 = int(starts[0])                                     # channel estimates of the first packet (the return triple)
