@@ -20,7 +20,8 @@
  *     concurrent calls on one context from different host threads / on
  *     different streams are safe (every call brings its own workspace and
  *     outputs; error text and diagnostics are kept per calling THREAD, not in
- *     the context).  The one exception is the legacy convenience
+ *     the context, and so are the 256 bytes of pinned host memory the calls
+ *     that return counts read them back into).  The one exception is the legacy convenience
  *     gf3_sync_stream_mode, which stores a default mode for the legacy entry
  *     point gf3_sync_stream; gf3_sync_stream_ex takes the mode per call.
  *   - complex128 arrays are interleaved (re, im) doubles, as NumPy stores them.
