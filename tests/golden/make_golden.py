@@ -315,10 +315,57 @@ def make_send_to_stream(OFDM):
                         payload_valid=np.packbits(pv.astype(np.uint8)), n_mask=len(sv), schmidlcox=sc, schmidlcox_error=sc_err)
 
 
+def make_peak_rule(OFDM):
+    """chirp_method's peak rule (OFDM.py:356-372) on streams built to exercise it: a ladder of chirp amplitudes around
+    the 0.4 threshold of the GLOBAL maximum, two chirps closer than a chirp length (the first detection suppresses the
+    larger one that follows), streams whose last chirp ends 0 .. 3 samples before the stream does (the except-branch wipes
+    every detection up to it), an inverted stream, and the ladder with noise.  int16 PCM values (exact in float64);
+    the expected output is the reference's `zeros` array as a list of indices."""
+    N, CP, P, D = 1024, 128, 1, 1
+    pts, bt = orc.qpsk_table()
+    K = N // 2 - 1
+    known = orc.load_known_bits(os.path.join(REF, "Handouts", "random_bits.txt"), 4096)
+    rx = reparam(OFDM.receiver(mode="A1", encoding="None", no_pilots=P, packet_length=D), N, CP, P, D, 1, K, pts, bt, known)
+    chirp = np.asarray(rx.sync_chirp(), dtype=np.float64)
+    Lc = len(chirp)
+    assert Lc == 5 * (N + CP)
+    rs = np.random.RandomState(11)
+
+    def stream(n, placed, noise=0.0, sign=1.0):
+        r = np.zeros(n)
+        for pos, g in placed:
+            m = min(Lc, n - pos)
+            r[pos:pos + m] += g * chirp[:m]
+        r = sign * r + noise * rs.randn(n)
+        return np.round(r / 0.25 * 20000.0).astype(np.int16)          # |chirp| <= 0.2: well inside int16
+
+    gap = Lc + 700
+    ladder = [(900 + i * gap, g) for i, g in enumerate([1.0, 0.45, 0.39, 0.41, 0.8, 0.2])]
+    cases = {
+        "ladder": stream(900 + 6 * gap + 300, ladder),
+        "ladder_noise": stream(900 + 6 * gap + 300, ladder, noise=0.004),
+        "close_pair": stream(3 * gap, [(500, 0.9), (500 + Lc // 2, 1.0), (500 + Lc // 2 + gap, 0.7)]),
+        # the correlation is "full", so the except-branch needs a detection within a chirp length of ITS end: a chirp that
+        # ends in the last samples of the stream.  Tails of 0 .. 3 samples pin where that starts and stops.
+        **{"tail%d" % t: stream(900 + 2 * gap + Lc + t, [(900, 1.0), (900 + gap, 0.8), (900 + 2 * gap, 0.9)]) for t in range(4)},
+        "inverted": stream(900 + 3 * gap, [(900, 1.0), (900 + gap, 0.6)], sign=-1.0),
+    }
+    out = {"N": N, "CP": CP, "Lc": Lc, "known_bits": known, "names": np.array(sorted(cases))}
+    for name in sorted(cases):
+        r16 = cases[name]
+        with np.errstate(all="ignore"):
+            zeros = rx.chirp_method(r16.astype(np.float64))
+        pk = np.flatnonzero(zeros)
+        print(f"g11_peak_rule[{name}]: n={len(r16)} peaks={pk}")
+        out["r_" + name] = r16
+        out["peaks_" + name] = pk
+    np.savez_compressed(os.path.join(HERE, "g11_peak_rule.npz"), **out)
+
+
 def main():
     OFDM = import_reference()
     make_known_bits()
-    which = set(sys.argv[1:]) or {"g1", "g1b", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"}
+    which = set(sys.argv[1:]) or {"g1", "g1b", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"}
     h = np.loadtxt(os.path.join(REF, "Handouts", "gr5channel.csv")).reshape(-1)
     if "g1" in which:
         make_loopback(OFDM, "g1_n1024_qpsk", 1024, 128, 2, 8, 2, 2, seed=1)
@@ -346,6 +393,8 @@ def main():
         make_demap_edges(OFDM)
     if "g6" in which:
         make_realrec(OFDM)
+    if "g11" in which:
+        make_peak_rule(OFDM)
 
 
 def make_config1(OFDM):

@@ -348,6 +348,24 @@ def test_facade_final_system_test_known_answer(capsys):
     assert np.abs(Hs_c - Hstart).max() <= 1e-12 * np.abs(Hstart).max() and np.abs(He_c - Hend).max() <= 1e-12 * np.abs(Hend).max()
 
 
+@pytest.mark.parametrize("storage", ["int16", "float64", "float32"])
+def test_peak_rule_fixture_every_sync_path(storage):
+    """The reference's chirp_method outputs of g11 (amplitude ladder around 0.4 of the global maximum, a larger chirp
+    suppressed by an earlier smaller one, the except-branch at tails of 0 .. 3 samples, an inverted stream) against the
+    all-fp64 path, the screened path and the general screening kernel, on the PCM values and on their float copies."""
+    g = load("g11_peak_rule")
+    pts, bt = orc.qpsk_table()
+    p = orc.RxParams(N=int(g["N"]), CP=int(g["CP"]), P=1, D=1, lo=1, hi=int(g["N"]) // 2 - 1, const_points=pts, const_bits=bt,
+                     known_bits=g["known_bits"])
+    eng = engine_for(p, in_dtype=getattr(torch, storage))
+    for name in g["names"]:
+        x = torch.from_numpy(g["r_" + str(name)].astype(storage)).cuda()
+        want = g["peaks_" + str(name)]
+        for mode in (1, 2, 3):
+            got = eng.sync_stream(x, mode=mode).cpu().numpy()
+            assert np.array_equal(got, want), (str(name), storage, mode, got, want)
+
+
 def test_config1_64_frames():
     """BASELINE config 1 geometry end to end on the GPU, bit-exact vs the reference."""
     g = load("g1b_config1_64f")

@@ -146,6 +146,23 @@ def test_real_recording_known_answer():
     np.testing.assert_allclose(out["Hs"][0], g["Hs0"], rtol=0, atol=1e-12 * np.abs(g["Hs0"]).max())
 
 
+def test_peak_rule_fixture():
+    """chirp_method (OFDM.py:356-372) on the reference-generated streams of g11: an amplitude ladder around the 0.4
+    threshold of the GLOBAL maximum, a chirp suppressed by an earlier, smaller one, the except-branch at tails of
+    0 .. 3 samples, an inverted stream."""
+    g = load("g11_peak_rule")
+    pts, bt = orc.qpsk_table()
+    p = orc.RxParams(N=int(g["N"]), CP=int(g["CP"]), P=1, D=1, lo=1, hi=int(g["N"]) // 2 - 1, const_points=pts, const_bits=bt,
+                     known_bits=g["known_bits"])
+    assert p.Lc == int(g["Lc"])
+    for name in g["names"]:
+        r = g["r_" + str(name)].astype(np.float64)
+        with np.errstate(all="ignore"):
+            got = np.flatnonzero(orc.chirp_method(r, p))
+        assert np.array_equal(got, g["peaks_" + str(name)]), name
+    assert len(g["peaks_tail0"]) == 0 and len(g["peaks_tail1"]) == 0 and len(g["peaks_tail2"]) == 3      # (the boundary the fixture pins)
+
+
 def test_schmidl_cox_matches_reference():
     g = load("g9_schmidlcox")
     p = orc.RxParams(N=4096, CP=224)
