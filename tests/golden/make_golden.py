@@ -344,6 +344,8 @@ def make_peak_rule(OFDM):
     cases = {
         "ladder": stream(900 + 6 * gap + 300, ladder),
         "ladder_noise": stream(900 + 6 * gap + 300, ladder, noise=0.004),
+        # the same amplitudes with the global maximum LAST: what passes is only known once the whole stream has been seen
+        "ladder_rev": stream(900 + 6 * gap + 300, [(900 + i * gap, g) for i, g in enumerate([0.2, 0.8, 0.41, 0.39, 0.45, 1.0])]),
         "close_pair": stream(3 * gap, [(500, 0.9), (500 + Lc // 2, 1.0), (500 + Lc // 2 + gap, 0.7)]),
         # the correlation is "full", so the except-branch needs a detection within a chirp length of ITS end: a chirp that
         # ends in the last samples of the stream.  Tails of 0 .. 3 samples pin where that starts and stops.
