@@ -310,6 +310,43 @@ def final_system_test_leg(reps=20, warm=3, cpu=True):
     return {"final_system_test": out}
 
 
+def pcm16_leg(args, cfg, big, payload, steps=20, warm=3):
+    """The headline step on the SAME packets stored as 16-bit PCM (the format recordings arrive in) instead of
+    f32: half the sample bytes, the same arithmetic.  A secondary figure -- `value` stays the f32-stored one SURVEY 8(d)
+    prescribes -- and a test of the energy budget of DESIGN 8.0, which prices the bytes that no longer move."""
+    import dataclasses
+    from gf3_audio_modem_amd import Engine
+    F = big.shape[0]
+    scale = 20000.0 / float(big.abs().max())
+    big16 = torch.empty(big.shape, dtype=torch.int16, device=big.device)
+    rows = 4096
+    for i in range(0, F, rows):                                   # (piecewise: no second f32 copy of the batch)
+        big16[i:i + rows] = torch.round(big[i:i + rows] * scale).to(torch.int16)
+    eng16 = Engine(dataclasses.replace(cfg, in_dtype=torch.int16))
+    bits = torch.empty((F, eng16.bytes_per_frame), dtype=torch.uint8, device=big.device)
+    starts = torch.empty((F,), dtype=torch.int64, device=big.device)
+
+    def step():
+        eng16.sync_frames(big16, F, args.stride, WIN_LO, WIN_LO + args.window, out_starts=starts)
+        eng16.demod_frames(big16, starts, out_bits=bits)
+    for _ in range(warm):
+        step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(steps):
+        step()
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / steps
+    errs = int((bits != payload).sum().item())                    # (bytes that differ: 0 means every bit is right)
+    n_samples = F * args.stride
+    del big16, eng16
+    return {"pcm16_storage": {"workload": f"the headline step on the same {F} packets stored as int16 PCM (scaled to +-20000) instead of f32",
+                              "ms_per_step": ms, "value": n_samples / (ms * 1e-3), "unit": "samples/s", "steps": steps,
+                              "payload_bytes_wrong": errs, "sample_bytes_per_step": 2 * n_samples}}
+
+
 def _event_ms(fn, reps=20, warm=3):
     """SURVEY 8(d) protocol for the secondary legs: MEDIAN HIP-event time of `fn` (one launch on the current stream)
     over `reps` >= 20 launches after `warm` = 3 untimed ones, in ms"""
@@ -532,6 +569,7 @@ def main():
                          "through a one-rank RCCL group; a rehearsal of the multi-GPU path, not the headline number")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 rFFT / soft-demap roofline legs (N=1)")
     ap.add_argument("--no-stream", action="store_true", help="skip the config-3 stream-sync roofline leg (N=1)")
+    ap.add_argument("--no-pcm16", action="store_true", help="skip the leg that repeats the step on int16-stored samples (N=1)")
     ap.add_argument("--no-final-system-test", action="store_true", help="skip the leg that runs the reference's own recording through the drop-in class (N=1)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-ingest (pinned, chunked H2D + stream receive) leg (N=1)")
     ap.add_argument("--gather-algo", default=None, help="N>1: NCCL_ALGO for the all-gather (e.g. Ring, Tree, Direct), set before the "
@@ -735,6 +773,8 @@ def main():
     extra = {}
     if world == 1 and not multi:
         del run.bits
+        if not args.no_pcm16:
+            extra.update(pcm16_leg(args, cfg, big, payload))
         if not args.no_config5:
             extra.update(demod_16qam_roofline(dev, args))
             extra.update(config5_rooflines(dev))
