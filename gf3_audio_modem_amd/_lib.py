@@ -80,7 +80,7 @@ def load():
     path = lib_path()
     from . import build as _build
     if not os.environ.get("GF3_LIB") and _build.stale():
-        # missing, or built from other sources than gf3rx.hip / gf3rx_device.h / gf3rx_screen.h / gf3rx.h as they are now
+        # missing, or built from other sources than csrc/*.hip, csrc/*.h and include/gf3rx.h as they are now
         # (the library carries the SHA-256 of what it was built from): compile it here if the ROCm toolchain is present
         # (same gfx950 build as __graft_entry__.build(), temp file + rename under a lock); otherwise fail loudly --
         # kernels that do not match the source must not run, and there is no other implementation to fall back to

@@ -27,17 +27,7 @@
 // realised ratio on random, DC-biased and adversarial streams (it stays below 2 u).
 #pragma once
 #include "gf3rx_device.h"
-
-typedef float2 cf;
-#define GF3_SCR_NC 4096              /* complex points of the screening transform (8192 real samples per window) */
-#define GF3_SCR_T 256                /* threads per workgroup: 16 points each */
-#define GF3_SCR_B 4                  /* adjacent output blocks per workgroup (share their windows' transforms) */
-#define GF3_SCR_CELL 14              /* centre lags per refinement cell (16 fp64 values with the two neighbours) */
-#define GF3_SCR_GAMMA (256.0f * 5.9604645e-8f)
-// Samples below 1e-19 have squares that underflow in fp32: a sum of 8192 rounded squares can miss 8192 x 1.4e-45 of
-// the true energy.  Added under the root, the energy stays an UPPER bound of |x|_2^2 whatever the samples' size (a stream
-// that small then has bounds far above its own correlation, lists everything and takes the fp64 path).
-#define GF3_SCR_UFLOW 2e-41f
+#include "gf3rx_screen_defs.h"
 
 GF3_DEV cf cfmk(float a, float b) { return make_float2(a, b); }
 GF3_DEV cf cfadd(cf a, cf b) { return cfmk(a.x + b.x, a.y + b.y); }
@@ -130,27 +120,6 @@ GF3_DEV void scr_fft4096(cf (&v)[16], cf* P, cf* Q, cf tw2, cf tw3, int t) {
     scr_dft16(v);
 }
 
-struct ScreenArgs {
-    const void* in; int64_t n_in; int dt;
-    const cf* tw;              // [4096] exp(-2 pi i m / 4096)
-    const cf* twn;             // [2049] exp(-2 pi i k / 8192)
-    const float4* Hs;          // [Q][8][256]: (H_q[k], H_q[4096 - k]), k = t + 256 r  (thread 0, r = 0: bin 2048 twice)
-    const float* H0N;          // [Q][2]: H_q[0], H_q[4096] (real)
-    const float* Hinf;         // [Q] max_k |H_q[k]|, rounded up
-    int Q, H, Lc;
-    int64_t nblk, plen;
-    float* P32;                // [plen]
-    float* blk_max;            // [nblk] max of the block's P32
-    float* blk_err;            // [nblk] bound on |P32 - P| for every lag of the block
-    int* run_lo;               // optional: running lower bound of the maximum (float bits, > 0), shared by the grid
-    float thresh;              // 0 < thresh < 1 enables skipping the store of blocks that cannot matter
-    // band-limited kernel (scr_ring_kernel) only:
-    const float4* Hb;          // [Q][GF3_SCR_KS / 2][256]: (H_q[k], H_q[k + 256]), k = t + 512 p  -- the bins below 256 GF3_SCR_KS
-    const float* ecoef;        // [2][Q] error per unit |x|_2: GF3_SCR_GAMMA (max|H_q| + |h_q,out|_2); per unit |x_out|_2: |h_q,out|_2
-    int R;                     // output blocks per workgroup
-    unsigned long long* bad;   // optional: bit 0 is set when a window's energy is not finite in fp32 (NaN / Inf samples, or
-                               // finite ones beyond 1e19): the bounds mean nothing then and the caller takes the fp64 path
-};
 
 // one window: samples -> spectrum slots.  X[2r] = X[k_r], X[2r+1] = X[4096 - k_r], k_r = t + 256 r (thread 0, r = 0:
 // both slots hold bin 2048); thread 0 also gets DC and Nyquist in z0 = (X[0], X[4096]).  Returns this thread's
@@ -406,8 +375,6 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ols_kernel(ScreenArgs a) {
 // transform per window -- 2 + (Q - 1) / R transforms per block where scr_ols_kernel, which has to re-transform the
 // Q + B - 1 windows under its B = 4 blocks, needs 3.25 (Q = 6) -- and 6 instead of 16 multiply-adds per partition.
 // Used when Q <= RQ and the dropped share is small (build_screen_plan); otherwise scr_ols_kernel.
-#define GF3_SCR_KS 6                 /* slots t + 256 r, r < KS, of the half spectrum are kept (even: read in pairs) */
-#define GF3_SCR_RQ 8                 /* ring depth = largest Q */
 template <int DT>
 __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
     extern __shared__ double2 smem[];
@@ -627,195 +594,9 @@ __global__ __launch_bounds__(GF3_SCR_T, 2) void scr_ring_kernel(ScreenArgs a) {
     }
 }
 
-// ---------------------------------------------------------------- screening bookkeeping
-struct ScrMisc {                  // device-resident scalars of one gf3_sync_stream call (zeroed by the host before the screen)
-    double Mlo;                   // best lower bound of the maximum: max_b (blk_max - blk_err)
-    double M;                     // the maximum (fp64 re-evaluation)
-    double lim;                   // listing level: a lag whose upper bound stays below it can neither be the maximum nor pass the threshold
-    long long ncell;              // cells listed (and re-evaluated)
-    long long nhit;               // of those, cells that hold a candidate
-    long long status;             // bit 0: the work list overflowed -> the caller falls back to the all-fp64 path
-    unsigned long long mlo_key;   // running maximum of (blk_max - blk_err) as an ordered key (0: none yet)
-    unsigned long long m_key;     // running maximum of the fp64 values, same encoding
-    unsigned int mlo_done;        // workgroups of scr_mlo_kernel that have contributed
-    unsigned int m_nan;           // a re-evaluated lag was NaN (np.amax then returns NaN)
-    long long total;              // length of the list being scanned (cells, then candidates)
-    long long np[2];              // pk_nms: peaks accepted, suppression status -- everything the host reads back is in this block
-};
-// order-preserving map double -> uint64 (every finite or infinite value maps above 0, so 0 can mean "nothing yet")
-GF3_DEV unsigned long long scr_key(double x) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-GF3_DEV double scr_unkey(unsigned long long k) {
-    if (k == 0) return -INFINITY;
-    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
-}
-
-// One list serves both questions.  With Mlo <= M:  a lag that could be the maximum has an upper bound >= Mlo, a lag
-// that could pass the threshold has one >= thresh M (1 - 1e-6) >= thresh Mlo (1 - 1e-6); so every lag that matters has
-// an upper bound >= lim = min(Mlo, thresh Mlo (1 - 1e-6)), known BEFORE any fp64 value is.  The cells under those lags
-// are re-evaluated once; M is the largest of their fp64 values and the rule is then applied to the same values.
-// (A few dozen workgroups: one workgroup's loop over 80 000 blocks was 40 us of load latency.  The last one to
-//  contribute turns the key into Mlo and lim.)
-#define SCR_MLO_THREADS 256
-__global__ __launch_bounds__(SCR_MLO_THREADS) void scr_mlo_kernel(const float* blk_max, const float* blk_err, int64_t nblk, ScrMisc* misc, double thresh) {
-    __shared__ double scratch[16];
-    double m = -INFINITY;                                                     // (fmax drops NaN blocks here; their lags are kept by scr_flag_kernel)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nblk; i += (int64_t)gridDim.x * blockDim.x)
-        m = fmax(m, (double)blk_max[i] - (double)blk_err[i]);
-    m = block_max(m, scratch);
-    if (threadIdx.x == 0) {
-        if (m > -INFINITY) atomicMax(&misc->mlo_key, scr_key(m));
-        __threadfence();
-        if (atomicAdd(&misc->mlo_done, 1u) == gridDim.x - 1) {
-            __threadfence();
-            m = scr_unkey(atomicMax(&misc->mlo_key, 0ull));
-            misc->Mlo = m;
-            // (the prefilter of pk_candidates: only a positive finite maximum and threshold exclude anything)
-            const bool filt = m > 0.0 && thresh > 0.0 && m < INFINITY && thresh < INFINITY;
-            misc->lim = filt ? fmin(m, thresh * m * (1.0 - 1e-6)) : -INFINITY;
-        }
-    }
-}
-
-// Cells: cell c = centre lags m = 1 + 14 c .. 14 + 14 c of the full correlation (zeros-indices i = m - 1); its
-// refinement evaluates the 16 lags 14 c .. 14 c + 15.  A cell is listed when one of its lags (centres, plus lag 0
-// for cell 0 and the last lag for the last cell) has an upper bound P32 + E_b that reaches misc->lim.
-// scr_flag_kernel looks at the lags once: a workgroup covers 64 segments of 64 cells, leaves one 64-bit hit mask per
-// segment and the number of hits; after the scan of those numbers scr_scatter_kernel turns the masks into the ascending
-// list of cell numbers.  The four waves of a flag workgroup take every fourth segment and never wait for one another
-// inside the loop (a stream with a chirp every 78 000 samples has one or two active blocks, four to eight active
-// segments, under a workgroup).
-#define SCR_LIST_THREADS 256
-#define SCR_LIST_SEGS 64             /* segments of 64 cells per workgroup: 4096 cells = 57 344 lags */
-__global__ __launch_bounds__(SCR_LIST_THREADS) void scr_flag_kernel(const float* __restrict__ P32, const float* __restrict__ blk_max,
-                                                                    const float* __restrict__ blk_err, int H, int64_t plen, int64_t ncell,
-                                                                    const ScrMisc* misc, unsigned long long* masks, int64_t* counts) {
-    __shared__ int wsum[SCR_LIST_THREADS / 64];
-    __shared__ unsigned long long blkmask;
-    const double level = misc->lim;
-    const bool all = !(level == level);                                      // NaN level: nothing can be excluded
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // Which of the (at most 64) output blocks under this workgroup's lags can reach the level at all: one parallel
-    // look, shared through LDS.  Most lags of a stream lie under blocks that cannot.
-    // (first block by a double multiplication and a correction: a 64-bit division is a hundred instructions, and most
-    //  workgroups do nothing else)
-    const int64_t L0 = GF3_SCR_CELL * (int64_t)blockIdx.x * SCR_LIST_SEGS * 64;       // < 2^53: exact as a double
-    int64_t b_first = (int64_t)((double)L0 * (1.0 / (double)H));
-    if (b_first * (int64_t)H > L0) --b_first;
-    if ((b_first + 1) * (int64_t)H <= L0) ++b_first;
-    if (wave == 0) {
-        const int64_t bb = b_first + lane;
-        const bool act = bb * (int64_t)H < plen && ((double)blk_max[bb] + (double)blk_err[bb] >= level);
-        const unsigned long long m = __ballot(act);
-        if (lane == 0) blkmask = all ? ~0ull : m;
-    }
-    __syncthreads();
-    const unsigned long long bm = blkmask;
-    if (bm == 0) { if (threadIdx.x == 0) counts[blockIdx.x] = 0; return; }   // (the masks are not read when the count is 0)
-    // Which of this wave's 16 segments touch a block that can reach the level: lane i answers for segment wave + 4 i
-    // (the blocks under its lags [14 c0, 14 (c0 + 64) + 2), 32-bit arithmetic relative to the workgroup's first block),
-    // then the wave walks the set bits only.
-    unsigned todo;
-    {
-        const int64_t c0 = ((int64_t)blockIdx.x * SCR_LIST_SEGS + wave + 4 * (lane & 15)) * 64;
-        const unsigned rel0 = (unsigned)(GF3_SCR_CELL * c0 - b_first * (int64_t)H);
-        const int r0 = (int)(rel0 / (unsigned)H), r1 = (int)((rel0 + GF3_SCR_CELL * 64 + 1) / (unsigned)H);
-        const unsigned long long span = (r1 >= 63 ? ~0ull : ((1ull << (r1 + 1)) - 1ull)) & ~((1ull << r0) - 1ull);
-        todo = (unsigned)(__ballot(lane < 16 && c0 < ncell && (bm & span) != 0) & 0xffffull);
-    }
-    unsigned long long keep = 0;                                             // lane i: mask of segment wave + 4 i
-    while (todo) {                                                           // (uniform over the wave)
-        const int si = __ffs((int)todo) - 1;
-        todo &= todo - 1;
-        const int64_t c0 = ((int64_t)blockIdx.x * SCR_LIST_SEGS + wave + 4 * si) * 64;
-        const int64_t c = c0 + lane;
-        bool hit = false;
-        if (c < ncell) {
-            int64_t lo = GF3_SCR_CELL * c + 1, hi = lo + GF3_SCR_CELL;       // centres [lo, hi)
-            if (c == 0) lo = 0;
-            if (c == ncell - 1) hi = plen;
-            if (hi > plen) hi = plen;
-            // block of the first lag by one 32-bit division relative to the workgroup's first block; at most one
-            // boundary can fall inside a cell (H >= 1024 > 16)
-            const unsigned rel = (unsigned)(lo - b_first * (int64_t)H);
-            int64_t bb = b_first + rel / (unsigned)H;
-            int64_t bend = (bb + 1) * (int64_t)H;
-            const float e0 = blk_err[bb];
-            const float e1 = (bend < hi) ? blk_err[bb + 1] : e0;
-            // a lag counts only if its own block can reach the level: blocks that cannot were possibly never written
-            const bool a0 = all | ((double)blk_max[bb] + (double)e0 >= level);
-            const bool a1 = (bend < hi) ? (all | ((double)blk_max[bb + 1] + (double)e1 >= level)) : a0;
-            // all (at most 16) lags are fetched before any is looked at -- a short-circuiting loop would serialise
-            // sixteen HBM round trips -- and fetched whether or not their block was written (what an unwritten block
-            // holds is ignored below), so that these loads do not wait for the block bounds above either
-            float pv[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) pv[j] = P32[lo + j < hi ? lo + j : hi - 1];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double up = (double)pv[j] + (double)((lo + j >= bend) ? e1 : e0);
-                hit = hit | ((lo + j < hi) & ((lo + j >= bend) ? a1 : a0) & ((up >= level) | !(up == up)));  // (a NaN keeps the lag)
-            }
-            hit = hit || all;
-        }
-        const unsigned long long bal = __ballot(hit);
-        if (lane == si) keep = bal;
-    }
-    if (lane < SCR_LIST_SEGS / 4) masks[(int64_t)blockIdx.x * SCR_LIST_SEGS + wave + 4 * lane] = keep;
-    int n = __popcll(keep);
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);              // (lanes 16 .. 63 hold 0)
-    if (lane == 0) wsum[wave] = n;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = (int64_t)wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-// One wave per flag workgroup: segment masks + the workgroup's offset -> cell numbers in ascending order.  Workgroup 0
-// also publishes the list length and raises the overflow flag.
-__global__ __launch_bounds__(64) void scr_scatter_kernel(const unsigned long long* masks, const int64_t* counts, const int64_t* offsets,
-                                                         const int64_t* total, ScrMisc* misc, int64_t* cells, int64_t cap) {
-    const long long n = total[0];
-    if (blockIdx.x == 0 && threadIdx.x == 0) { misc->ncell = n; if (n > cap) misc->status |= 1; }
-    if (n > cap || counts[blockIdx.x] == 0) return;
-    const int lane = threadIdx.x;
-    unsigned long long m = masks[(int64_t)blockIdx.x * SCR_LIST_SEGS + lane];
-    const int pc = __popcll(m);
-    int x = pc;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
-    int64_t o = offsets[blockIdx.x] + (x - pc);
-    const int64_t c0 = ((int64_t)blockIdx.x * SCR_LIST_SEGS + lane) * 64;
-    while (m) {
-        const int j = __ffsll((long long)m) - 1;
-        cells[o++] = c0 + j;                                                 // (o < n <= cap)
-        m &= m - 1;
-    }
-}
-
 // fp64 re-evaluation of the 16 lags of one cell: P[m] = sum_k r[m - Lc + 1 + k] c[k], m = 14 c + j, j = 0..15.
 // Each thread takes a contiguous range of taps and slides a 31-sample window over them, 16 taps at a time
 // (256 fma per 31 sample loads + 16 tap loads); the 16 partial sums are then reduced over the workgroup.
-template <int DT> struct ScrStage { typedef float S; };      // what scr_refine_kernel stages a sample as
-template <> struct ScrStage<DT_F64> { typedef double S; };
-struct RefineArgs {
-    const void* in; int64_t n_in; int dt;
-    const double* chirp; int Lc;
-    const int64_t* cells; ScrMisc* misc;
-    int64_t plen;
-    double* cell_val;             // [ncell][16] the cell's fp64 lags (their maximum goes to misc->m_key / m_nan)
-    const double* chirp_t;        // the taps tiled for scr_refine_kernel: [step][q < 8][lane][2] = c[1024 step + 16 lane + 2 q + (0, 1)], 0 past Lc
-    unsigned long long* stamps;   // diagnostic build only (-DGF3_STAMPS): [waves][8] s_memtime ticks summed per phase (tools/ab/refine_stamps.py)
-};
-#ifdef GF3_STAMPS
-// s_memtime once everything the wave has in flight on the scalar / LDS side has returned; nothing is scheduled across it
-#define SCR_TICK(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); \
-                         __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define SCR_TICK(t) do { } while (0)
-#endif
-#define SCR_REF_THREADS 256
-#define SCR_REF_WT 1024                              /* taps per wave and step: 16 per lane */
 // Every WAVE works on its own: it walks its cells' taps 1024 at a time and owns a private slice of LDS for the samples, so
 // there is no workgroup barrier anywhere.  What the first version of this kernel (rounds 1-2: samples AND taps staged
 // through LDS as doubles, 57 LDS instructions per step; cells drawn from a work counter) was bound by was measured in
@@ -1111,47 +892,6 @@ __global__ __launch_bounds__(SCR_REF_THREADS) void scr_refine_mfma_kernel(Refine
             if (nanb) atomicOr(&a.misc->m_nan, 1u);
             else if (mx > -INFINITY) atomicMax(&a.misc->m_key, scr_key(mx));
         }
-    }
-}
-
-// candidates of every listed cell: the reference's rule on the fp64 values, division by the maximum first
-// (OFDM.py:359-361).  One thread per cell; bit j of the mask: zeros-index 14 c + j is a candidate.
-__global__ void scr_decide_kernel(const int64_t* cells, const double* cell_val, ScrMisc* misc, int64_t nz, double thresh,
-                                  unsigned* cell_mask, int64_t* cell_cnt) {
-    if (misc->status & 1) return;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const double M = misc->m_nan ? NAN : scr_unkey(misc->m_key);          // (np.amax propagates NaN)
-    if (i == 0) misc->M = M;
-    if (i >= misc->ncell) return;
-    const int64_t m0 = GF3_SCR_CELL * cells[i];
-    double p[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) p[j] = cell_val[i * 16 + j] / M;
-    unsigned mk = 0;
-#pragma unroll
-    for (int j = 0; j < GF3_SCR_CELL; ++j) {
-        const bool cand = (m0 + j < nz) && ((p[j + 1] - p[j]) * (p[j + 2] - p[j + 1]) <= 0.0) && (p[j + 1] > thresh);
-        mk |= cand ? (1u << j) : 0u;
-    }
-    cell_mask[i] = mk;
-    cell_cnt[i] = __popc(mk);
-    if (mk) atomicAdd((unsigned long long*)&misc->nhit, 1ull);
-}
-
-// ordered expansion of the cell masks into zeros-indices
-__global__ void scr_expand_kernel(const int64_t* cells, const unsigned* cell_mask, const int64_t* offsets, const ScrMisc* misc,
-                                  int64_t* cand, int64_t cap) {
-    if (misc->status & 1) return;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= misc->ncell) return;
-    unsigned m = cell_mask[i];
-    int64_t o = offsets[i];
-    const int64_t base = GF3_SCR_CELL * cells[i];
-    while (m) {
-        const int j = __ffs((int)m) - 1;
-        if (o < cap) cand[o] = base + j;
-        ++o;
-        m &= m - 1;
     }
 }
 

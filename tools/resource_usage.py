@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Tabulate hipcc's -Rpass-analysis=kernel-resource-usage remarks (registers, spills, scratch, occupancy, LDS)
 per kernel.   hipcc ... -Rpass-analysis=kernel-resource-usage ... 2> res.txt ; python tools/resource_usage.py res.txt
-With no argument: compiles gf3rx.hip itself (add --dev for the quick N=4096-only GF3_DEV_BUILD)."""
+With no argument: compiles the library's translation units itself (--unit=NAME for one of them; --dev for the quick
+N=4096-only GF3_DEV_BUILD)."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -25,12 +26,18 @@ if __name__ == "__main__":
     else:
         with tempfile.TemporaryDirectory() as d:
             sys.path.insert(0, ROOT)
-            from gf3_audio_modem_amd.build import FLAGS                      # exactly the flags the library is built with
-            cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ["-I" + os.path.join(ROOT, "include"),
-                   "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(d, "x.so"), os.path.join(ROOT, "gf3_audio_modem_amd", "csrc", "gf3rx.hip")]
-            if "--dev" in sys.argv:
-                cmd.insert(1, "-DGF3_DEV_BUILD")
-            txt = subprocess.run(cmd, capture_output=True, text=True).stderr
+            from concurrent.futures import ThreadPoolExecutor
+            from gf3_audio_modem_amd.build import CFLAGS, CSRC, SRC         # exactly the flags the library is built with
+            only = [a[7:] for a in sys.argv[1:] if a.startswith("--unit=")]  # e.g. --unit=gf3rx_demod_qpsk
+            units = [u for u in SRC if not only or os.path.splitext(os.path.basename(u))[0] in only]
+            def one(u):
+                cmd = ["/opt/rocm/bin/hipcc"] + CFLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                       "-Rpass-analysis=kernel-resource-usage", "-c", u, "-o", os.path.join(d, os.path.basename(u) + ".o")]
+                if "--dev" in sys.argv:
+                    cmd.insert(1, "-DGF3_DEV_BUILD")
+                return subprocess.run(cmd, capture_output=True, text=True).stderr
+            with ThreadPoolExecutor(8) as pool:
+                txt = "".join(pool.map(one, units))
     if "--demangle" in sys.argv or True:
         pass
     print(f"{'VGPR':>4} {'AGPR':>4} {'SGPR':>4} {'sSpl':>4} {'vSpl':>4} {'scr':>4} {'occ':>3} {'LDS':>6}  kernel")
