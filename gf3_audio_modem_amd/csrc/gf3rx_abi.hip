@@ -563,25 +563,32 @@ extern "C" int gf3_rfft_batch(gf3_ctx* c, const void* d_in, int64_t n_in, const 
     return GF3_OK;
 }
 
-extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,
-                                uint8_t* d_bits, void* d_eq, void* d_Hs, void* d_He, double* d_slope, void* d_Hest,
-                                int32_t* d_status, void* stream) {
+extern "C" int gf3_demod_frames_ex(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,
+                                   uint8_t* d_bits, void* d_eq, void* d_Hs, void* d_He, double* d_slope, void* d_Hest,
+                                   int32_t* d_status, void* d_work, int32_t mode, void* stream) {
     DeviceGuard dg(c);
     if (c && F == 0) return GF3_OK;
-    if (!c || !d_in || !d_off || !d_bits || F < 0) return fail(c, GF3_EINVAL, "gf3_demod_frames: bad argument");
+    if (!c || !d_in || !d_off || !d_bits || F < 0 || mode < 0 || mode > 2) return fail(c, GF3_EINVAL, "gf3_demod_frames: bad argument");
     const gf3_config& g = c->cfg;
     DemodArgs a{{c->d_tw, c->d_twn}, d_in, n_in, d_off, g.in_dtype,
                 g.CP, c->S, g.P, g.D, c->K, g.C, g.mu, g.M,
                 c->d_known, c->d_pos, c->contig_lo, demod_ring(c), c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, (cplx*)d_eq, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, d_status,
-                nullptr, nullptr, nullptr, nullptr, c->qpsk_q, c->ug, c->stamps};
+                nullptr, nullptr, nullptr, nullptr, c->qpsk_q, c->ug, c->stamps, 0, 0, nullptr};
+    // long packets, few at a time: pilot sums, estimate and data symbols as three launches (gf3rx_demod_split.hip)
+    if (d_work && demod_wants_split(c, F, mode)) return demod_split(c, a, F, d_work, (hipStream_t)stream);
     hipError_t e = hipSuccess;
     if (d_eq || d_Hest) e = launch_demod_full(c, a, F, (hipStream_t)stream);
     else if (c->qpsk_q > 0.0) e = launch_demod_qpsk(c, a, F, (hipStream_t)stream);
     else e = launch_demod_scan(c, a, F, (hipStream_t)stream);
     HIPCHK(c, e);
     return GF3_OK;
+}
+extern "C" int gf3_demod_frames(gf3_ctx* c, const void* d_in, int64_t n_in, const int64_t* d_off, int64_t F,
+                                uint8_t* d_bits, void* d_eq, void* d_Hs, void* d_He, double* d_slope, void* d_Hest,
+                                int32_t* d_status, void* stream) {
+    return gf3_demod_frames_ex(c, d_in, n_in, d_off, F, d_bits, d_eq, d_Hs, d_He, d_slope, d_Hest, d_status, nullptr, 1, stream);
 }
 
 extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start, const void* d_end, int64_t F,
@@ -596,7 +603,7 @@ extern "C" int gf3_equalise(gf3_ctx* c, const void* d_data, const void* d_start,
                 c->d_known, c->d_pos, c->contig_lo, demod_ring(c), c->d_cre, c->d_cim, c->d_clab,
                 c->fit_lo, c->fit_hi, c->xbar, c->inv_sxx,
                 d_bits, c->row_bytes, nullptr, (cplx*)d_Hs, (cplx*)d_He, d_slope, (cplx*)d_Hest, nullptr,
-                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_q, c->ug, nullptr};
+                (const cplx*)d_data, (const cplx*)d_start, (const cplx*)d_end, (cplx*)d_eq_all, c->qpsk_q, c->ug, nullptr, 0, 0, nullptr};
     const hipError_t e = launch_demod_spectra(c, a, F, (hipStream_t)stream);
     HIPCHK(c, e);
     return GF3_OK;

@@ -118,9 +118,17 @@ template <int NC, int MODE> struct DemodOcc {
     static constexpr int MAG_ELEMS = MAG_LDS ? NC : 0;             // double2 (a0, da) per slot per thread: 8 * NC/8
 };
 
-template <int NC, int DT, bool SPECTRA, int MODE>
+// STAGE: the whole packet in one workgroup (STAGE_ALL, the batch path), or -- for long packets, few at a time -- its two
+// halves as separate launches (gf3rx_demod_split.hip): STAGE_EST stops after the channel estimate (input: the time-domain
+// pilot sums of pilot_sum_kernel; output: Hs, He, slope), STAGE_DATA takes that state from memory and demodulates the
+// data symbols [chunk Dc, (chunk + 1) Dc) of packet blockIdx.x / nchunk.  The discarded branches vanish: STAGE_ALL is
+// the kernel it was.
+enum { STAGE_ALL = 0, STAGE_EST = 1, STAGE_DATA = 2 };
+template <int NC, int DT, bool SPECTRA, int MODE, int STAGE = STAGE_ALL>
 __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kernel(DemodArgs a) {
     constexpr bool FULL = (MODE == MODE_FULL);
+    static_assert(STAGE == STAGE_ALL || !SPECTRA, "the two-phase form takes time-domain input");
+    static_assert(STAGE != STAGE_EST || DT == DT_F64, "the estimate stage reads the fp64 pilot sums");
     extern __shared__ double2 smem[];
     constexpr int T = NC / 8;
     // LDS: [scratch 32 doubles | start-up rotation tables | FFT buffer | decision bytes | (fit-range overflow)]
@@ -132,8 +140,14 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     // channel-estimate stage, whose fit-range arrays may run over this region
     double2* mags = (double2*)(labs + ((a.ring * a.C + 15) & ~15));
     const int tid = threadIdx.x;
-    const int64_t f = blockIdx.x;
+    int64_t f = blockIdx.x;
     const int K = a.K, P = a.P, D = a.D, S = a.S;
+    int l_lo = 0, l_hi = D;                                               // data symbols this workgroup demodulates
+    if constexpr (STAGE == STAGE_DATA) {
+        f = blockIdx.x / (unsigned)a.nchunk;
+        l_lo = (int)(blockIdx.x - (unsigned)f * (unsigned)a.nchunk) * a.Dc;
+        l_hi = min(D, l_lo + a.Dc);
+    }
     const int Bs = a.C * a.mu;                                            // bits per data symbol
     uint8_t* row = a.bits + f * (int64_t)a.row_bytes;
 
@@ -142,6 +156,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         off = a.off[f];
         const bool ok = off >= 0 && off + (int64_t)(2 * P + D) * S <= a.n_in;
         if (!ok) {                                                        // ragged packet
+            if constexpr (STAGE == STAGE_DATA) return;                    // (the estimate stage has zeroed the row)
             for (int i = tid; i < a.row_bytes; i += T) row[i] = 0;
             if (tid == 0 && a.status) atomicOr(a.status, 1);
             return;
@@ -167,11 +182,13 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     auto fetch = [&](int i) {
         typedef typename RawT<DT>::E E;
         const E* base = (const E*)a.in + (off + (int64_t)sym_pos(i) * S + a.CP);      // wave-uniform
+        if constexpr (STAGE == STAGE_EST) base = (const E*)a.psum + ((int64_t)f * 2 + i) * (2 * NC);   // "symbol" i = side i's pilot sum
         const unsigned t2 = 2u * (unsigned)launder(tid);
 #pragma unroll
         for (int r = 0; r < 8; ++r) nxt[r].load_u(base, t2 + 2u * (unsigned)(r * T));
     };
-    const int Msym = 2 * P + D;
+    const int Msym = STAGE == STAGE_EST ? 2 : (STAGE == STAGE_DATA ? 2 * P + l_hi : 2 * P + D);      // (nothing is fetched from here on)
+    const int Pl = STAGE == STAGE_EST ? 1 : P;                            // symbols summed per side
     cplx v[8], z0;
     auto transform = [&](int i) {                     // nxt -> spectrum slots in v; prefetch i+1
 #pragma unroll
@@ -187,7 +204,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     };
     GF3_STAMP(0);
     GF3_STAMP_RT(6);
-    if constexpr (!SPECTRA) fetch(0);
+    if constexpr (!SPECTRA) fetch(STAGE == STAGE_DATA ? 2 * P + l_lo : 0);
 
     // ---- pilots: Hs, He = mean over P symbols / known  (OFDM.py:443-451).
     // The mean of the P pilot spectra is the spectrum of the mean pilot symbol (the DFT is linear), so
@@ -205,12 +222,17 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) He[s2] = cadd(He[s2], v[s2]);
         }
+    } else if constexpr (STAGE == STAGE_DATA) {
+        // the estimate stage's Hs, He (true scale, divided by the known symbols): the same doubles the one-launch kernel
+        // holds in registers at this point, so u, a0, da below come out bit for bit the same
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) { Hs[s2] = a.Hs[f * K + bin_of(s2) - 1]; He[s2] = a.He[f * K + bin_of(s2) - 1]; }
     } else {
         for (int side = 0; side < 2; ++side) {
             cplx sum[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) sum[r] = cmk(0.0, 0.0);
-            for (int i = side * P; i < (side + 1) * P; ++i) {
+            for (int i = side * Pl; i < (side + 1) * Pl; ++i) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) sum[r] = cadd(sum[r], nxt[r].get());
                 if (i + 1 < Msym) fetch(i + 1);                    // next pilot, or the first data symbol
@@ -234,7 +256,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     // so the fit needs no prefix scan, and corrections before fit_lo (a common offset of every
     // fitted point) drop out: only carriers inside the fit range need their angles.
     GF3_STAMP(2);
-    lds_barrier();                                    // FFT buffer is free: reuse it for the fit-range carriers
+    if constexpr (STAGE != STAGE_DATA) lds_barrier();  // FFT buffer is free: reuse it for the fit-range carriers
     const int L = a.fit_hi - a.fit_lo;
     // [L] Hs of carrier fit_lo + j, later its angle in .x.  The two arrays start at the FFT buffer and may run on
     // over the decision bytes (not in use before the first data symbol) and beyond: demod_lds_bytes sizes it.
@@ -249,12 +271,16 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     const double invP = (1.0 / (double)P) / XS;
     // (a) straight-line over the 8 slots (independent chains overlap): H = mean/known, unit phasor, magnitudes
     cplx ik[8];                                       // 1/known (L2 latency covered by the other resident workgroup)
+    if constexpr (STAGE != STAGE_DATA) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
+        for (int s = 0; s < 8; ++s) ik[s] = a.inv_known[bin_of(s) - 1];
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        Hs[s] = cmul(cscale(Hs[s], invP), ik[s]);
-        He[s] = cmul(cscale(He[s], invP), ik[s]);
+        if constexpr (STAGE != STAGE_DATA) {
+            Hs[s] = cmul(cscale(Hs[s], invP), ik[s]);
+            He[s] = cmul(cscale(He[s], invP), ik[s]);
+        }
         const double m2 = Hs[s].x * Hs[s].x + Hs[s].y * Hs[s].y;
         const double ia = rsq_nr(m2);                                 // 1/|Hs|
         if constexpr (MODE != MODE_QPSK) {
@@ -267,6 +293,9 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     }
     // (b) optional dumps; the carriers inside the fit range go to LDS, where the angles are taken by
     //     whichever thread the carrier falls to (2 L angles per packet instead of 16 per thread)
+    double slope;
+    if constexpr (STAGE == STAGE_DATA) slope = a.slope[f];
+    else {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int bn = bin_of(s);
@@ -284,7 +313,6 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         hel[j].x = atan2_fast(h1.y, h1.x);
     }
     lds_barrier();
-    double slope;
     {
         double acc = 0.0;
         for (int j = launder(tid); j < L; j += T) {
@@ -299,6 +327,8 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         slope = block_sum(acc, scratch + 16) * a.inv_sxx;
     }
     if (tid == 0 && a.slope) a.slope[f] = slope;
+    }
+    if constexpr (STAGE == STAGE_EST) return;         // Hs, He, slope are in memory: the data stage takes it from there
     GF3_STAMP(3);
     if constexpr (DemodOcc<NC, MODE>::MAG_LDS && GF3_ABL == 0) {      // (block_sum's barriers: every thread is done with the fit-range arrays)
 #pragma unroll
@@ -370,7 +400,9 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     // from small two-level tables (n + 1 = 64 h + i  ->  T[64 + h] * T[i]) built once per packet.
     constexpr int NTH = NC / 64 + 1, NRT = 64 + NTH;
     {
-        const double phi0 = slope * ((0.5 * (double)P) / denom), dphi = slope / denom;
+        // (the data stage of the two-phase form starts its phasors at its first symbol: f_l at l = l_lo)
+        const double phi0 = STAGE == STAGE_DATA ? slope * (((double)l_lo + 0.5 * (double)P) / denom) : slope * ((0.5 * (double)P) / denom);
+        const double dphi = slope / denom;
         for (int i = tid; i < NRT; i += T) {
             const double nn = (double)(i < 64 ? i - 1 : 64 * (i - 64));
             rtab[i] = cis_fast(phi0 * nn);
@@ -396,10 +428,10 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 #pragma unroll
         for (int s = 0; s < 8; ++s) psl[s] = pos_of(s);
     }
-    for (int l = 0; l < D; ++l) {
+    for (int l = l_lo; l < l_hi; ++l) {
         if constexpr (SPECTRA) { lds_barrier(); load_spectra(a.sp_data + ((int64_t)f * D + l) * K); }
         else transform(2 * P + l);
-        if (l > 0) pack_words(l - 1, false);
+        if (l > l_lo) pack_words(l - 1, false);
         const double fl = ((double)l + 0.5 * (double)P) / denom;          // (l + P/2)/(D+P)
         uint8_t* lab_l = labs + (l & (a.ring - 1)) * C;
         if constexpr (MODE == MODE_QPSK) {
@@ -487,7 +519,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     }
     GF3_STAMP(4);
     lds_barrier();
-    pack_words(D - 1, ((D * Bs) & 31) != 0);
+    pack_words(l_hi - 1, l_hi == D && ((D * Bs) & 31) != 0);
     GF3_STAMP(5);
     GF3_STAMP_RT(7);
 }

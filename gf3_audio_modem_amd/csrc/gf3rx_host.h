@@ -3,7 +3,7 @@
 // Kernels live in per-family translation units compiled in parallel (gf3_audio_modem_amd/build.py):
 //   gf3rx_fft.hip            rfft_kernel, tx_kernel
 //   gf3rx_demod_{qpsk,scan,full}.hip   the three modes of demod_kernel (gf3rx_demod.h)
-//   gf3rx_demod_split.hip    the two-phase demodulation of long packets (gf3rx_demod_split.h)
+//   gf3rx_demod_split.hip, gf3rx_dsplit_{qpsk,scan,full}.hip   the two-phase demodulation of long packets
 //   gf3rx_corr.hip           corr_kernel, spec_kernel, ols_kernel
 //   gf3rx_screen.hip         scr_ring_kernel, scr_ols_kernel, scr_refine_kernel (gf3rx_screen.h)
 //   gf3rx_sync.hip           pk_*, ck_*, scr list kernels + gf3_sync_stream*, gf3_sync_chunk, gf3_sync_decide
@@ -76,6 +76,10 @@ struct DemodArgs {
     double qpsk_q;            // >0: table is the reference QPSK table (+-q +-qj): decide by signs away from ties
     UniGrid ug;
     unsigned long long* stamps;   // diagnostic build only (-DGF3_STAMPS): [F][8] s_memtime per phase
+    // two-phase form for long packets (gf3rx_demod_split.hip): the data stage runs nchunk workgroups per packet, each on
+    // Dc consecutive data symbols, from the channel state the estimate stage left in Hs / He / slope
+    int Dc, nchunk;
+    const double* psum;       // [F][2][N] time-domain sums of each side's P pilot symbols (input of the estimate stage)
 };
 
 #ifdef GF3_STAMPS
@@ -262,6 +266,12 @@ hipError_t launch_demod_qpsk(const gf3_ctx* c, const DemodArgs& a, int64_t F, hi
 hipError_t launch_demod_scan(const gf3_ctx* c, const DemodArgs& a, int64_t F, hipStream_t st);
 hipError_t launch_demod_full(const gf3_ctx* c, const DemodArgs& a, int64_t F, hipStream_t st);
 hipError_t launch_demod_spectra(const gf3_ctx* c, const DemodArgs& a, int64_t F, hipStream_t st);
+// gf3rx_demod_split.hip + gf3rx_dsplit_{qpsk,scan,full}.hip: the two-phase form for long packets, few at a time
+bool demod_wants_split(const gf3_ctx* c, int64_t F, int mode);
+int demod_split(const gf3_ctx* c, DemodArgs a, int64_t F, void* d_work, hipStream_t st);
+hipError_t launch_dsplit_qpsk(const gf3_ctx* c, const DemodArgs& a, int64_t grid, hipStream_t st);
+hipError_t launch_dsplit_scan(const gf3_ctx* c, const DemodArgs& a, int64_t grid, hipStream_t st);
+hipError_t launch_dsplit_full(const gf3_ctx* c, const DemodArgs& a, int64_t grid, hipStream_t st);
 // gf3rx_corr.hip
 hipError_t run_corr(const gf3_ctx* c, const CorrPlan& pl, const CorrArgs& a, int64_t grid, hipStream_t st);
 hipError_t run_spec_ols(const CorrPlan& pl, OlsArgs a, int64_t nwin, int64_t nblk, hipStream_t st);   // spec_kernel, then ols_kernel

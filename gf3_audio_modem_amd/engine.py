@@ -169,6 +169,7 @@ class Engine:
         self._h = h
         self._sync_mode = 0
         self._tls = threading.local()
+        self.n_cu = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
         self.bytes_per_frame = int(self.lib.gf3_bytes_per_frame(h))
         self.max_window = int(self.lib.gf3_sync_max_window(h))
 
@@ -224,9 +225,12 @@ class Engine:
         self._check(self.lib.gf3_rfft_batch(self._h, _ptr(x), x.numel(), _ptr(offsets), n, _ptr(out), self._stream()))
         return out
 
-    def demod_frames(self, x, frame_offsets, want=(), out_bits=None):
+    def demod_frames(self, x, frame_offsets, want=(), out_bits=None, split=None):
         """Fused a3-a10.  Returns dict with 'bits' (packed uint8
-        [F, bytes_per_frame]) plus any of 'eq','Hs','He','slope','Hest','status'."""
+        [F, bytes_per_frame]) plus any of 'eq','Hs','He','slope','Hest','status'.
+        split: None -- the library chooses between one packet per workgroup and the two-phase form for long packets,
+        few at a time (gf3_demod_frames_ex: pilot sums, estimate, data symbols spread over the chip; the reference's own
+        geometry of 3 packets x 220 symbols); False / True force the one or the other."""
         cfg = self.cfg
         x = self._samples(x)
         off = torch.as_tensor(frame_offsets, dtype=torch.int64).to(self.device).contiguous()
@@ -239,10 +243,25 @@ class Engine:
         if "slope" in want: o["slope"] = self._new((F,), torch.float64)
         if "Hest" in want: o["Hest"] = self._new((F, cfg.D, cfg.K), torch.complex128)
         if "status" in want: o["status"] = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        self._check(self.lib.gf3_demod_frames(
+        # the two-phase form needs a workspace (pilot sums, and Hs / He / slope when they are not asked for): only ever
+        # chosen for a few packets, so it is only allocated for a few
+        work = None
+        if split or (split is None and F * 4 <= self.n_cu):
+            work = self._new((int(self.lib.gf3_demod_workspace_bytes(self._h, F)),), torch.uint8)
+        self._check(self.lib.gf3_demod_frames_ex(
             self._h, _ptr(x), x.numel(), _ptr(off), F, _ptr(bits), _ptr(o.get("eq")), _ptr(o.get("Hs")),
-            _ptr(o.get("He")), _ptr(o.get("slope")), _ptr(o.get("Hest")), _ptr(o.get("status")), self._stream()))
+            _ptr(o.get("He")), _ptr(o.get("slope")), _ptr(o.get("Hest")), _ptr(o.get("status")),
+            _ptr(work), 0 if split is None else (2 if split else 1), self._stream()))
         return o
+
+    def demod_plan(self, F, split=None):
+        """How demod_frames(F packets, split=...) runs: dict(split: two-phase form or not, Dc: data symbols per workgroup of
+        its data stage, chunks: workgroups per packet)."""
+        dc, nch = C.c_int32(0), C.c_int32(0)
+        two = self.lib.gf3_demod_split_plan(self._h, int(F), 0 if split is None else (2 if split else 1), C.byref(dc), C.byref(nch))
+        if split is None and F * 4 > self.n_cu:
+            two = 0                                               # (no workspace is allocated for batches)
+        return dict(split=bool(two), Dc=int(dc.value), chunks=int(nch.value))
 
     def equalise(self, data, start, end, want=("Hest",)):
         """receiver.equalise on frequency-domain symbols [F,D,K], [F,P,K], [F,P,K]."""

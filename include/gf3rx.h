@@ -135,6 +135,29 @@ int gf3_demod_frames(gf3_ctx *ctx, const void *d_in, int64_t n_in,
                      double *d_slope, void *d_Hest, int32_t *d_status, void *stream);
 
 /*
+ * The same call with a workspace, which opens the TWO-PHASE form for LONG packets, FEW at a time -- the reference's
+ * own geometry (no_pilots = 20, packet_length = 180, OFDM.py:18; three packets in Final System Test.ipynb cell 7), where
+ * one packet per workgroup would leave the chip idle.  The triple loop of equalise (OFDM.py:466-478) is independent over
+ * (symbol, carrier) once Hest_start, Hest_end and the slope exist (OFDM.py:443-462), so: the pilot symbols of each side
+ * are summed in the time domain over F x 2 x N/512 workgroups, the channel estimate runs once per packet, and the
+ * data symbols of a packet are spread over ceil(D / Dc) workgroups that each pack their own word-aligned bit range.
+ * Outputs are those of gf3_demod_frames: Hs / He / slope bit for bit, equalised symbols to ~1e-13 (the phasor of a
+ * chunk's first symbol is computed directly instead of by recurrence), bits identical.
+ *   d_work   gf3_demod_workspace_bytes(ctx, F) bytes of device memory, or NULL (then always the one-launch kernel)
+ *   mode     0: the library chooses by F and D (two-phase when F <= CUs / 4 and a packet cuts into >= 4 chunks)
+ *            1: always the one-launch kernel      2: two-phase whenever d_work is given
+ */
+int64_t gf3_demod_workspace_bytes(const gf3_ctx *ctx, int64_t F);
+/* what gf3_demod_frames_ex(F, mode) does when it is given a workspace: returns 1 for the two-phase form (0: one launch)
+ * and stores the chunk length Dc (data symbols per workgroup) and the chunks per packet it would use */
+int gf3_demod_split_plan(const gf3_ctx *ctx, int64_t F, int32_t mode, int32_t *h_Dc, int32_t *h_nchunk);
+int gf3_demod_frames_ex(gf3_ctx *ctx, const void *d_in, int64_t n_in,
+                        const int64_t *d_frame_offsets, int64_t F,
+                        uint8_t *d_bits_packed, void *d_eq, void *d_Hs, void *d_He,
+                        double *d_slope, void *d_Hest, int32_t *d_status,
+                        void *d_work, int32_t mode, void *stream);
+
+/*
  * receiver.equalise as a stand-alone stage (OFDM.py:422-480): the same kernel
  * as gf3_demod_frames, fed with frequency-domain symbols instead of samples.
  *   d_data [F, D, K], d_start [F, P, K], d_end [F, P, K] complex128 (get_data's outputs)

@@ -1204,3 +1204,121 @@ def test_receive_host_fails_where_the_reference_fails():
         orc.receive(bad, p)
     with pytest.raises(ValueError):
         eng.receive_host(bad, chunk_samples=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the two-phase demodulation of long packets, few at a time (gf3_demod_frames_ex; gf3rx_demod_split.hip)
+# ---------------------------------------------------------------------------------------------------------------
+def _same_as_one_launch(eng, x, starts, want, rows=None):
+    """rows: the packets whose dumps are compared (a ragged packet's are left unwritten by both paths)"""
+    one = eng.demod_frames(x, starts, want=want, split=False)
+    two = eng.demod_frames(x, starts, want=want, split=True)
+    assert torch.equal(one["bits"], two["bits"])
+    rows = slice(None) if rows is None else rows
+    for k in ("Hs", "He", "slope"):                                 # the same doubles: the estimate stage IS the one-launch kernel's
+        if k in want:
+            assert torch.equal(one[k][rows], two[k][rows]), k
+    for k in ("eq", "Hest"):                                        # phasor at a chunk's first symbol: direct instead of by recurrence
+        if k in want:
+            a, b = one[k].cpu().numpy(), two[k].cpu().numpy()
+            assert np.abs(a - b).max() <= 1e-12 * max(1.0, float(np.abs(a).max())), k
+    if "status" in want:
+        assert int(one["status"].item()) == int(two["status"].item())
+    return one, two
+
+
+@pytest.mark.parametrize("storage", ["u8", "f64"])
+def test_split_path_on_the_real_recording(storage):
+    """The reference's own test geometry (P = 20, D = 180, three packets): the library picks the two-phase form by
+    itself, and it returns the one-launch path's Hs / He / slope bit for bit, its bits, eq within 1e-12 -- and the
+    reference's bits."""
+    g = load("g6_realrec")
+    p = modeA2_params(g["known_bits"])
+    r = g["wav_u8"] if storage == "u8" else g["wav_u8"] / 1.0
+    eng = engine_for(p, in_dtype=torch.uint8 if storage == "u8" else torch.float64)
+    plan = eng.demod_plan(3)
+    assert plan["split"] and plan["chunks"] >= 4 and (plan["Dc"] * p.C * p.mu) % 32 == 0, plan
+    x = torch.from_numpy(r).cuda()
+    starts = torch.from_numpy(np.asarray(g["peaks"][:-1]) + 2).cuda()
+    one, two = _same_as_one_launch(eng, x, starts, ("eq", "Hest", "Hs", "He", "slope"))
+    lean_one, lean_two = _same_as_one_launch(eng, x, starts, ("Hs", "He", "slope"))
+    assert torch.equal(lean_two["bits"], two["bits"])
+    auto = eng.demod_frames(x, starts)                               # no dumps asked for: state lives in the workspace
+    assert torch.equal(auto["bits"], two["bits"])
+    bits = eng.unpack_bits(auto["bits"]).cpu().numpy()
+    ref = orc.receive(g["wav_u8"] / 1.0, p)
+    assert np.array_equal(bits, ref["bits"])
+    assert np.abs(two["eq"].cpu().numpy() - ref["eq"]).max() <= 1e-9 * float(np.abs(ref["eq"]).max())
+
+
+@pytest.mark.parametrize("name", LOOPBACKS)
+def test_split_path_on_the_loopback_fixtures(name):
+    """Every reference fixture through the forced two-phase form (short packets: one chunk per packet, the estimate
+    stage and the state hand-over are what is exercised), all three modes of the data stage."""
+    g = load(name)
+    p = params_of(g)
+    eng = engine_for(p)
+    x = torch.from_numpy(g["r"]).cuda()
+    starts = torch.from_numpy(np.asarray(g["peaks"][:-1]) + 2).cuda()
+    one, two = _same_as_one_launch(eng, x, starts, ("eq", "Hs", "He", "slope", "Hest", "status"))
+    lean = eng.demod_frames(x, starts, split=True)
+    assert torch.equal(lean["bits"], two["bits"])
+    assert np.array_equal(eng.unpack_bits(lean["bits"]).cpu().numpy(), unpack(g))
+    assert np.abs(two["eq"].cpu().numpy() - g["eq"]).max() <= 1e-9 * max(1.0, float(np.abs(g["eq"]).max()))
+
+
+@pytest.mark.parametrize("N,C,mu,D,P,dt", [(1024, 333, 2, 40, 3, torch.float64),      # q = 16: chunks of 16, 16, 8; odd word count
+                                           (1024, 7, 4, 50, 1, torch.float32),        # 28 bits per symbol: q = 8, words span symbols
+                                           (2048, 1, 2, 70, 2, torch.int16),          # one carrier: q = 16
+                                           (4096, 1400, 2, 37, 5, torch.float32),     # the reference band, D odd
+                                           (8192, 4095, 6, 12, 2, torch.float32),     # 64-QAM, every carrier, N = 8192
+                                           (2048, 500, 4, 9, 4, torch.uint8)])        # 16-QAM on 8-bit samples
+def test_split_path_round_trip_geometries(N, C, mu, D, P, dt):
+    """TX -> two-phase RX returns the payload, and equals the one-launch path, for chunk lengths forced by
+    32 / gcd(C mu, 32), partial last words, words spanning several symbols, every FFT size and sample storage."""
+    pts, bt = orc.qpsk_table() if mu == 2 else orc.square_qam_table(mu)
+    K = N // 2 - 1
+    known = np.tile(load("g6_realrec")["known_bits"], -(-K * mu // 4096))
+    lo = 1 if C == K else 50
+    p = orc.RxParams(N=N, CP=N // 16, P=P, D=D, lo=lo, hi=lo + C, const_points=pts, const_bits=bt.astype(np.int64),
+                     known_bits=known, fit_lo=60, fit_hi=min(400, K))
+    F = 3
+    eng_tx = engine_for(p, in_dtype=torch.float64)
+    gen = torch.Generator(device="cuda").manual_seed(N + C + mu)
+    packed = torch.randint(0, 256, (F, eng_tx.bytes_per_frame), dtype=torch.uint8, device="cuda", generator=gen)
+    nbits = D * C * mu
+    if nbits % 8:
+        packed[:, -1] &= (0xFF << (8 - nbits % 8)) & 0xFF             # bits past the payload stay zero
+    filler = np.zeros(K, dtype=complex)
+    rs = np.random.RandomState(C)                                    # (random filler: a constant one is an impulse in time, which 8-bit storage would clip everything else under)
+    filler[np.delete(np.arange(K), p.data_carriers - 1)] = rs.choice(np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2), size=K - C)
+    rows = eng_tx.tx_frames(packed, filler, out_dtype=torch.float64)
+    if dt in (torch.int16, torch.uint8):
+        amp = float(rows.abs().max())
+        q = rows * ((20000.0 if dt == torch.int16 else 100.0) / amp)
+        rows_q = (q.round() + (128 if dt == torch.uint8 else 0)).to(dt)
+    else:
+        rows_q = rows.to(dt)
+    eng = engine_for(p, in_dtype=dt)
+    starts = torch.arange(F, device="cuda") * rows.shape[1] + p.Lc
+    plan = eng.demod_plan(F, split=True)
+    assert (plan["Dc"] * C * mu) % 32 == 0 or plan["chunks"] == 1, plan
+    one, two = _same_as_one_launch(eng, rows_q, starts, ("eq", "Hs", "He", "slope", "status"))
+    lean = eng.demod_frames(rows_q, starts, split=True)
+    assert torch.equal(lean["bits"], packed)
+    assert torch.equal(two["bits"], packed)
+
+
+def test_split_path_ragged_packet_and_status():
+    """A packet that runs past the stream decodes to zero bits and raises the status bit in the two-phase form too
+    (the estimate stage zeroes the row, the data stage leaves it alone)."""
+    g = load("g7_n4096_qpsk_drift")
+    p = params_of(g)
+    eng = engine_for(p)
+    x = torch.from_numpy(g["r"]).cuda()
+    good = np.asarray(g["peaks"][:-1]) + 2
+    starts = torch.from_numpy(np.concatenate([good, [len(g["r"]) - 100, -5]])).cuda()
+    one, two = _same_as_one_launch(eng, x, starts, ("slope", "Hs", "He", "status"), rows=slice(0, len(good)))
+    assert int(two["status"].item()) == 1
+    assert int(two["bits"][len(good):].sum()) == 0
+    assert np.array_equal(eng.unpack_bits(two["bits"][: len(good)]).cpu().numpy(), unpack(g))
