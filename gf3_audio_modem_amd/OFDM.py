@@ -343,21 +343,14 @@ class receiver(transmitter):
             return torch.bitwise_xor(b, k).cpu().numpy()
         return bits_encoded
 
-    def _decode_device(self, bits_u8):
-        """decode() for receive(): the 0/1 decisions are still on the device, so the XOR runs there and the int64 array the
-        reference returns crosses PCIe once, into pinned memory that becomes the numpy array (decode() itself, handed a host
-        array, has to upload it first)."""
+    def _decode_packed(self, eng, packed):
+        """PS + decode of receive(): the packed decisions are still on the device; one kernel unpacks them, applies the
+        XOR mask and writes the int64 array the reference returns straight into pinned host memory (gf3_unpack_bits).
+        Returns a CPU tensor over that memory: valid after the caller's synchronisation."""
         if self.encoding == "LDPC":
             raise NotImplementedError("LDPC decoding is out of scope (pyldpc; marked broken in the reference, OFDM.py:21)")
-        b = bits_u8.to(torch.int64)
-        if self.encoding == "XOR":
-            n = b.numel()
-            known = torch.as_tensor(np.asarray(self.known_sequence[: self.data_bits_per_symbol], dtype=np.int64)).to(b.device)
-            b = torch.bitwise_xor(b, known.repeat(-(-n // len(known)))[:n])
-        out = torch.empty(b.numel(), dtype=torch.int64, pin_memory=True)
-        out.copy_(b, non_blocking=True)
-        torch.cuda.current_stream(b.device).synchronize()
-        return out.numpy()
+        mask = np.asarray(self.known_sequence[: self.data_bits_per_symbol], dtype=np.uint8) if self.encoding == "XOR" else None
+        return eng.unpack_decode(packed, mask)
 
     # ---- whole receive chain (OFDM.py:581-657) ----------------------------------------
     def receive(self, signal, graph_output=False):
@@ -379,19 +372,28 @@ class receiver(transmitter):
         self.no_packets = int(starts.numel())
         if self.no_packets == 0:
             raise ValueError("need at least one array to concatenate")
-        L = (2 * self.no_pilots + self.packet_length) * (self.cp_length + self.ofdm_symbol_size)
-        if int(starts.max()) + L > len(r):
+        want = ("Hs", "He", "slope", "status") + (("Hest", "eq") if graph_output else ())
+        o = eng.demod_frames(x, starts, want=want)
+        bits_t = self._decode_packed(eng, o["bits"])
+        # everything else the host needs, in ONE small copy behind the kernels: first packet's Hs / He, the slopes, and the
+        # ragged-packet flag (a packet that runs past the recording: the reference's get_symbols fails on it)
+        K, F = self.K, self.no_packets
+        small = torch.cat([torch.view_as_real(o["Hs"][0]).reshape(-1), torch.view_as_real(o["He"][0]).reshape(-1), o["slope"],
+                           o["status"].to(torch.float64)])
+        host = torch.empty(small.numel(), dtype=torch.float64, pin_memory=True)
+        host.copy_(small, non_blocking=True)
+        torch.cuda.current_stream(small.device).synchronize()
+        if host[-1] != 0:                                       # (before anything is printed: get_symbols fails first in the reference)
             raise ValueError("all the input array dimensions except for the concatenation axis must match exactly")
         print("Number of received OFDM symbols:    " + str(self.no_packets * self.packet_length))
-        want = ("Hs", "He", "slope") + (("Hest", "eq") if graph_output else ())
-        o = eng.demod_frames(x, starts, want=want)
-        bits = self._decode_device(eng.unpack_bits(o["bits"]))
-        self._last_slope = o["slope"].cpu().numpy()
+        bits = bits_t.numpy()
+        h = host.numpy()
+        Hest_start0, Hest_end0 = h[: 2 * K].view(np.complex128).copy(), h[2 * K: 4 * K].view(np.complex128).copy()
+        self._last_slope = h[4 * K: 4 * K + F].copy()
         print("Number of received bits:            " + str(len(bits)))
-        Hest_start, Hest_end = o["Hs"].cpu().numpy(), o["He"].cpu().numpy()
         if graph_output:
-            self._plots(o["Hest"].cpu().numpy(), Hest_start, Hest_end, o["eq"].cpu().numpy())
-        return bits, Hest_start[0], Hest_end[0]
+            self._plots(o["Hest"].cpu().numpy(), o["Hs"].cpu().numpy(), o["He"].cpu().numpy(), o["eq"].cpu().numpy())
+        return bits, Hest_start0, Hest_end0
 
     def _receive_chunked(self, eng, r, chunk):
         try:
@@ -403,7 +405,9 @@ class receiver(transmitter):
         starts = (res["peaks"] + 2)[:-1]
         self.no_packets = int(starts.numel())
         print("Number of received OFDM symbols:    " + str(self.no_packets * self.packet_length))
-        bits = self._decode_device(eng.unpack_bits(res["bits"]))
+        bits_t = self._decode_packed(eng, res["bits"])
+        torch.cuda.current_stream(res["bits"].device).synchronize()
+        bits = bits_t.numpy()
         print("Number of received bits:            " + str(len(bits)))
         L = (2 * self.no_pilots + self.packet_length) * (self.cp_length + self.ofdm_symbol_size)
         s0 = int(starts[0])                                     # channel estimates of the first packet (the return triple)

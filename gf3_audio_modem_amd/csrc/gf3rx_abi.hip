@@ -835,6 +835,52 @@ static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, ui
     HIPCHK(c, hipGetLastError());
     return GF3_OK;
 }
+// ============================================================================
+// PS + decode (OFDM.py:504-505, 541-544): packed decisions -> the int64 0/1 array the reference returns, whitening
+// mask applied.  A thread owns two consecutive output elements (one 16-byte store; a wave writes 1 KB contiguously),
+// which is what lets the destination be pinned HOST memory written over PCIe by the kernel itself.
+// ============================================================================
+struct UnpackArgs { const uint8_t* packed; int row_bytes; int64_t bpf, total; const uint8_t* mask; int n_mask; long long* out; };
+__global__ __launch_bounds__(256) void unpack_bits_kernel(UnpackArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; 2 * t < a.total; t += stride) {
+        long long v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t e = 2 * t + h;                               // output index = global bit number
+            const int64_t f = e / a.bpf, j = e - f * a.bpf;            // packet, bit inside the packet
+            unsigned bit = e < a.total ? (a.packed[f * a.row_bytes + (j >> 3)] >> (7 - (int)(j & 7))) & 1u : 0u;
+            if (a.mask) bit ^= a.mask[e % a.n_mask] & 1u;              // tile(mask)[:len] runs over the whole stream
+            v[h] = (long long)bit;
+        }
+        if (2 * t + 1 < a.total) *(longlong2*)(a.out + 2 * t) = make_longlong2(v[0], v[1]);
+        else a.out[2 * t] = v[0];
+    }
+}
+extern "C" int gf3_unpack_bits(gf3_ctx* c, const uint8_t* d_bits, int64_t F, const uint8_t* d_mask, int32_t n_mask, void* out, void* stream) {
+    DeviceGuard dg(c);
+    if (c && F == 0) return GF3_OK;
+    if (!c || !d_bits || !out || F < 0 || (d_mask && n_mask < 1) || ((uintptr_t)out & 15)) return fail(c, GF3_EINVAL, "gf3_unpack_bits: bad argument (out must be 16-byte aligned)");
+    // where does `out` live?  Device memory is used as it is; pinned host memory through its device-side address; anything
+    // else (pageable memory) cannot be written by a kernel
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, out) != hipSuccess) { (void)hipGetLastError(); return fail(c, GF3_EINVAL, "gf3_unpack_bits: out is neither device memory nor pinned host memory"); }
+    void* dst = out;
+    if (at.type == hipMemoryTypeHost) {
+        dst = at.devicePointer;
+        if (!dst) return fail(c, GF3_EINVAL, "gf3_unpack_bits: the pinned host buffer is not mapped into the device's address space");
+    } else if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged && at.type != hipMemoryTypeUnified)
+        return fail(c, GF3_EINVAL, "gf3_unpack_bits: out is neither device memory nor pinned host memory");
+    const int64_t bpf = (int64_t)c->cfg.D * c->cfg.C * c->cfg.mu;
+    UnpackArgs a{d_bits, c->row_bytes, bpf, F * bpf, d_mask, n_mask, (long long*)dst};
+    int64_t grid = (a.total / 2 + 255) / 256;
+    if (grid > 8 * (int64_t)c->n_cu) grid = 8 * (int64_t)c->n_cu;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(unpack_bits_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
+    HIPCHK(c, hipGetLastError());
+    return GF3_OK;
+}
+
 extern "C" int gf3_demap_hard(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* d_bits, uint8_t* d_idx, void* stream) {
     DeviceGuard dg(c);
     if (c && n == 0) return GF3_OK;

@@ -650,6 +650,27 @@ class Engine:
         receive_host keeps them between calls so that a receiver fed one recording after another does not allocate."""
         self._tls.ingest = None
 
+    # ------------------------------------------------------------------ PS + decode (OFDM.py:504-505, 541-544)
+    def unpack_decode(self, packed, mask_bits=None, to_host=True):
+        """[F, bytes_per_frame] packed decisions -> the int64 0/1 array receiver.receive returns (packet -> symbol ->
+        carrier -> bit), XORed with tile(mask_bits)[:len] when a whitening mask is given.  to_host: the kernel writes
+        straight into pinned host memory (gf3_unpack_bits) and a torch CPU tensor over that memory is returned -- valid
+        once the stream has been synchronised; else a device tensor."""
+        packed = packed.contiguous()
+        F = packed.shape[0]
+        n = F * self.cfg.bits_per_frame
+        mask = None
+        if mask_bits is not None:
+            key = bytes(np.asarray(mask_bits, dtype=np.uint8))
+            cached = getattr(self, "_mask_cache", None)
+            if cached is None or cached[0] != key:
+                cached = self._mask_cache = (key, torch.from_numpy(np.frombuffer(key, dtype=np.uint8).copy()).to(self.device))
+            mask = cached[1]
+        out = torch.empty(n, dtype=torch.int64, pin_memory=True) if to_host else self._new((n,), torch.int64)
+        self._check(self.lib.gf3_unpack_bits(self._h, _ptr(packed), F, _ptr(mask), 0 if mask is None else mask.numel(),
+                                             C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     # ------------------------------------------------------------------ bit helpers (layout only)
     def unpack_bits(self, packed):
         """[F, bytes_per_frame] uint8 -> [F * D*C*mu] uint8 0/1 (np.unpackbits order), on device."""

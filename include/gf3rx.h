@@ -309,6 +309,18 @@ int gf3_equalise_known_h(gf3_ctx *ctx, const void *d_in, int64_t n_in, const int
                          const double *d_h, int32_t n_taps, void *d_eq_c128, uint8_t *d_bits_u8,
                          uint8_t *d_idx_u8_or_null, void *d_work, void *stream);
 
+/*
+ * PS + decode (OFDM.py:504-505, 541-544) on the packed decisions of gf3_demod_frames: one int64 0/1 per bit, in the
+ * reference's order (packet -> symbol -> data carrier -> bit), XORed with the whitening mask when one is given --
+ * `bits ^ tile(known_sequence[:C*mu])[:len]` for encoding "XOR", d_mask_u8 = NULL for encoding "None".
+ *   d_bits_packed [F, gf3_bytes_per_frame] uint8     d_mask_u8 [n_mask] one byte per bit (0/1), or NULL
+ *   out_i64       [F * D*C*mu] int64: DEVICE memory, or PINNED host memory (hipHostMalloc / hipHostRegister -- e.g. a
+ *                 torch tensor with pin_memory=True): the kernel then writes the array the reference returns straight
+ *                 into host memory, 16 bytes per lane, and no separate copy is needed.  Pageable host memory is refused.
+ */
+int gf3_unpack_bits(gf3_ctx *ctx, const uint8_t *d_bits_packed, int64_t F, const uint8_t *d_mask_u8, int32_t n_mask,
+                    void *out_i64, void *stream);
+
 /* max-log soft demapping (not in the reference; LLR > 0 <=> bit 0). [n*mu] f32 */
 int gf3_soft_demap(gf3_ctx *ctx, const void *d_sym_c128, int64_t n,
                    double noise_var, float *d_llr_f32, void *stream);

@@ -59,6 +59,10 @@ def import_reference():
     sys.path[:0] = [st, REF]
     os.chdir(d)
     import OFDM  # noqa
+    # (matplotlib asks a LOADED IPython for its shell when a figure is first made; the stand-in has served its purpose --
+    #  `from IPython.display import Audio` at the top of OFDM.py -- and is taken out of the module table again)
+    for m in ("IPython.display", "IPython"):
+        sys.modules.pop(m, None)
     return OFDM
 
 
@@ -258,6 +262,21 @@ def make_realrec(OFDM):
     sha = hashlib.sha256(bits.astype(np.uint8).tobytes()).hexdigest()
     print("g6_realrec: BER", repr(ber), "sha", sha, "peaks", np.flatnonzero(zeros), "slopes", slopes)
     assert repr(float(ber)) == "0.023375665289067146"
+    # The notebook's other calls on the same run (cells 7-9): receive(..., graph_output=True), save_file(rx_bits),
+    # channel_response(Hstart) -- what they print, return and write (file names; the saved file's bytes by hash)
+    import glob
+
+    def new_files(fn, *a, **k):
+        before = set(glob.glob("plots/*") + glob.glob("output_files/*"))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            out = fn(*a, **k)
+        return out, sorted(set(glob.glob("plots/*") + glob.glob("output_files/*")) - before), buf.getvalue()
+    (bits_g, _, _), plots_receive, receive_stdout = new_files(rx.receive, r, graph_output=True)
+    assert np.array_equal(bits_g, bits)
+    (save_name, save_data), saved, save_stdout = new_files(OFDM.save_file, bits)
+    _, plots_channel, _ = new_files(rx.channel_response, Hs0)
+    print("g6_realrec notebook calls:", plots_receive, saved, repr(save_stdout), plots_channel)
     np.savez_compressed(
         os.path.join(HERE, "g6_realrec.npz"),
         wav_u8=raw.astype(np.uint8), fs=fs,
@@ -266,6 +285,10 @@ def make_realrec(OFDM):
         bits=np.packbits(bits.astype(np.uint8)), n_bits=len(bits),
         src_bits=np.packbits(src.astype(np.uint8)), n_src=len(src),
         Hs0=Hs0, He0=He0, known_bits=rx.known_sequence.astype(np.uint8),
+        receive_stdout=receive_stdout, plots_receive=np.array(plots_receive), save_stdout=save_stdout, save_name=save_name,
+        save_files=np.array(saved), save_data_len=len(save_data),
+        save_data_sha256=hashlib.sha256(np.asarray(save_data, dtype=np.uint8).tobytes()).hexdigest(),
+        plots_channel=np.array(plots_channel),
     )
 
 

@@ -1322,3 +1322,73 @@ def test_split_path_ragged_packet_and_status():
     assert int(two["status"].item()) == 1
     assert int(two["bits"][len(good):].sum()) == 0
     assert np.array_equal(eng.unpack_bits(two["bits"][: len(good)]).cpu().numpy(), unpack(g))
+
+
+def test_notebook_calls_graph_output_channel_response_save_file(tmp_path, monkeypatch, capsys):
+    """Cells 7-9 of `Final System Test.ipynb` as the notebook makes them, on the GPU path: receive(r, graph_output=True)
+    (OFDM.py:615-654: the full-dump mode of the demodulator feeds the two plots), save_file(rx_bits) (:766-794) and
+    channel_response(Hstart) (:553-577).  What the unmodified reference prints, returns and writes for these calls is in
+    the g6 fixture (tests/golden/make_golden.py ran them)."""
+    import os
+    import matplotlib
+    matplotlib.use("Agg", force=True)
+    import matplotlib.pyplot as plt
+    plt.switch_backend("Agg")
+    from gf3_audio_modem_amd.OFDM import receiver, save_file
+    g = load("g6_realrec")
+    monkeypatch.chdir(tmp_path)
+    r = g["wav_u8"] / 1.0                                            # notebook cell 5
+    rx = receiver(mode="A2", encoding="XOR")
+    capsys.readouterr()
+    rx_bits, Hstart, Hend = rx.receive(r, graph_output=True)         # cell 7
+    assert capsys.readouterr().out == str(g["receive_stdout"])
+    assert hashlib.sha256(rx_bits.astype(np.uint8).tobytes()).hexdigest() == str(g["sha256_bits"])
+    assert rx_bits.dtype == np.int64 and len(rx_bits) == int(g["n_bits"])
+    assert np.abs(Hstart - g["Hs0"]).max() <= 1e-11 * np.abs(g["Hs0"]).max()
+    assert np.abs(Hend - g["He0"]).max() <= 1e-11 * np.abs(g["He0"]).max()
+    for f in g["plots_receive"].tolist():
+        assert os.path.getsize(f) > 1000, f
+    src = np.unpackbits(g["src_bits"])[: int(g["n_src"])]            # cell 8
+    errs = np.sum(abs(src.astype(np.int64) - rx_bits[: len(src)]))
+    assert "{}".format(errs / len(src)) == str(g["ber_str"])
+    name, data = save_file(rx_bits)
+    assert capsys.readouterr().out == str(g["save_stdout"])
+    assert name == str(g["save_name"]) and len(data) == int(g["save_data_len"])
+    assert hashlib.sha256(np.asarray(data, dtype=np.uint8).tobytes()).hexdigest() == str(g["save_data_sha256"])
+    for f in g["save_files"].tolist():
+        assert hashlib.sha256(open(f, "rb").read()).hexdigest() == str(g["save_data_sha256"]), f
+    rx.channel_response(Hstart)                                      # cell 9
+    for f in g["plots_channel"].tolist():
+        assert os.path.getsize(f) > 1000, f
+    plt.close("all")
+
+
+@pytest.mark.parametrize("C,mu,D", [(1400, 2, 180), (7, 3, 5), (333, 2, 3)])
+def test_unpack_decode_kernel_matches_numpy(C, mu, D):
+    """gf3_unpack_bits (PS + decode, OFDM.py:504-505, 541-544): int64 0/1 in the reference's order, XOR with
+    tile(mask)[:len]; into device memory and straight into pinned host memory; odd bits-per-packet (padded rows);
+    pageable host memory is refused."""
+    import ctypes
+    pts, bt = orc.qpsk_table() if mu == 2 else (np.exp(2j * np.pi * np.arange(8) / 8), np.array([[(i >> 2) & 1, (i >> 1) & 1, i & 1] for i in range(8)]))
+    K = 2047
+    known = np.tile(load("g6_realrec")["known_bits"], -(-K * mu // 4096))
+    p = orc.RxParams(N=4096, CP=224, P=2, D=D, lo=100, hi=100 + C, const_points=pts, const_bits=np.asarray(bt).astype(np.int64), known_bits=known)
+    eng = engine_for(p)
+    F = 5
+    rs = np.random.RandomState(C)
+    bits = rs.randint(0, 2, (F, D * C * mu)).astype(np.uint8)
+    packed = torch.from_numpy(np.stack([np.packbits(b) for b in bits])).cuda()
+    assert packed.shape[1] == eng.bytes_per_frame
+    mask = known[: C * mu]
+    want_plain = bits.reshape(-1).astype(np.int64)
+    want_xor = want_plain ^ np.resize(mask, want_plain.shape).astype(np.int64)
+    for m, want in ((None, want_plain), (mask, want_xor)):
+        dev = eng.unpack_decode(packed, m, to_host=False)
+        host = eng.unpack_decode(packed, m, to_host=True)
+        torch.cuda.synchronize()
+        assert dev.dtype == torch.int64 and np.array_equal(dev.cpu().numpy(), want)
+        assert not host.is_cuda and host.is_pinned() and np.array_equal(host.numpy(), want)
+    pageable = np.zeros(want_plain.size + 2, dtype=np.int64)
+    addr = pageable.ctypes.data + (-pageable.ctypes.data) % 16
+    rc = eng.lib.gf3_unpack_bits(eng._h, ctypes.c_void_p(packed.data_ptr()), F, None, 0, ctypes.c_void_p(addr), None)
+    assert rc == -1 and b"pinned" in eng.lib.gf3_last_error(None)

@@ -233,3 +233,27 @@ def test_bench_cpu_baseline_inputs_decode_to_their_payload():
     r, pk, payload, _ = bench._config3_stream(F=4)
     out = orc.receive(r, orc.RxParams(**pk))
     assert len(out["starts"]) == 4 and np.mean(out["bits"] != payload) < 0.01
+
+
+def test_facade_file_framing_matches_the_reference_record(tmp_path, monkeypatch, capsys):
+    """save_file / load_file of the drop-in module are host-side NumPy (OFDM.py:756-794): on the reference's decoded bits
+    of the real recording (g6) save_file prints, returns and writes what the unmodified reference did (recorded by
+    tests/golden/make_golden.py), and load_file of the written file frames it back to the same header + bytes."""
+    import hashlib
+    from gf3_audio_modem_amd.OFDM import load_file, save_file
+    g = load("g6_realrec")
+    bits = np.unpackbits(g["bits"])[: int(g["n_bits"])].astype(np.int64)
+    monkeypatch.chdir(tmp_path)
+    capsys.readouterr()
+    name, data = save_file(bits)
+    assert capsys.readouterr().out == str(g["save_stdout"])
+    assert name == str(g["save_name"]) and len(data) == int(g["save_data_len"])
+    assert hashlib.sha256(np.asarray(data, dtype=np.uint8).tobytes()).hexdigest() == str(g["save_data_sha256"])
+    (path,) = g["save_files"].tolist()
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == str(g["save_data_sha256"])
+    import os
+    os.makedirs("input_files")
+    os.replace(path, os.path.join("input_files", name))
+    framed = load_file(name)
+    hdr = f"{name}\0{len(data)}\0".encode("latin-1")
+    assert np.array_equal(np.packbits(framed), np.concatenate([np.frombuffer(hdr, np.uint8), data]))

@@ -31,8 +31,8 @@ print("demod_frames, event-timed: one launch %.3f ms   two-phase %.3f ms   (auto
     EV(lambda: eng.demod_frames(x, starts, want=("Hs", "He", "slope"), split=False)),
     EV(lambda: eng.demod_frames(x, starts, want=("Hs", "He", "slope"), split=True)),
     EV(lambda: eng.demod_frames(x, starts, want=("Hs", "He", "slope")))))
-t_dec, bits = T(lambda: rx._decode_device(eng.unpack_bits(o["bits"])))
+t_dec, bits = T(lambda: rx._decode_packed(eng, o["bits"]))
 t_h, _ = T(lambda: (o["Hs"].cpu().numpy(), o["He"].cpu().numpy(), o["slope"].cpu().numpy()))
 with contextlib.redirect_stdout(io.StringIO()):
     t_all, _ = T(lambda: rx.receive(wav))
-print("upload %.3f  sync_stream %.3f  starts.max %.3f  demod_frames %.3f  unpack+xor+D2H %.3f  Hs/He/slope D2H %.3f  | receive() %.3f ms" % (t_up, t_sync, t_mx, t_dem, t_dec, t_h, t_all))
+print("upload %.3f  sync_stream %.3f  starts.max %.3f  demod_frames %.3f  unpack+xor into pinned host memory %.3f  Hs/He/slope D2H %.3f  | receive() %.3f ms" % (t_up, t_sync, t_mx, t_dem, t_dec, t_h, t_all))
