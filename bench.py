@@ -81,25 +81,128 @@ class PowerSampler:
         return float(np.median(self.samples)) if self.samples else None
 
 
-def build_workload(args, rank):
+def build_workload(args, rank, N=4096, frames=None, stride=None):
     """F distinct frame buffers, synthesised on the device by the engine's own transmit kernel
     (gf3_tx_frames): random payload, jitter gap 0..299 before each chirp, QPSK filler on the one
-    non-data carrier.  Returns the rows and what the receiver must recover."""
+    non-data carrier.  Returns the rows and what the receiver must recover.  (N, frames, stride: the same
+    geometry -- CP = N/8, P = 2, D = 8, QPSK on bins 1..K-1 -- at another symbol size, for the by-N legs.)"""
     from gf3_audio_modem_amd import Engine, RxConfig, qpsk_table
-    N, CP, P, D = 4096, 512, 2, 8
+    CP, P, D = N // 8, 2, 8
     K = N // 2 - 1
+    frames = frames or args.frames
+    stride = stride or args.stride
     pts, bt = qpsk_table()
     known = np.unpackbits(np.load(os.path.join(ROOT, "gf3_audio_modem_amd", "data", "known_bits.npz"))["packed"])
+    known = np.tile(known, -(-K * 2 // len(known)))
     cfg = RxConfig(N=N, CP=CP, P=P, D=D, data_bins=np.arange(1, K), const_points=pts, const_bits=bt,
                    known_bits=known, in_dtype=torch.float32, max_window=args.window)
     eng = Engine(cfg)
     gen = torch.Generator(device="cuda").manual_seed(20261003 + rank)
-    payload = torch.randint(0, 256, (args.frames, eng.bytes_per_frame), dtype=torch.uint8, device="cuda", generator=gen)
-    gaps = torch.randint(0, 300, (args.frames,), dtype=torch.int64, device="cuda", generator=gen)
+    payload = torch.randint(0, 256, (frames, eng.bytes_per_frame), dtype=torch.uint8, device="cuda", generator=gen)
+    gaps = torch.randint(0, 300, (frames,), dtype=torch.int64, device="cuda", generator=gen)
     filler = np.zeros(K, dtype=complex)
     filler[K - 1] = pts[(20261003 + rank) % 4]                  # random_qpsk for the unused carrier (OFDM.py:201-215)
-    big = eng.tx_frames(payload, filler, stride=args.stride, gaps=gaps, out_dtype=torch.float32)
+    big = eng.tx_frames(payload, filler, stride=stride, gaps=gaps, out_dtype=torch.float32)
     return eng, cfg, big, payload, gaps
+
+
+def by_N_rooflines(dev, args, reps=20):
+    """The two fused kernels of the headline step at the other symbol sizes SURVEY section 2 generalises to
+    (OFDM.py:27 hard-codes 4096): N in {1024, 2048, 8192} with the headline's geometry scaled (CP = N/8, P = 2, D = 8,
+    QPSK on bins 1..K-1, chirp 5 (N + CP), f32 samples, jitter gaps 0..299, 320-lag window) and the SAME number of
+    stream samples per launch -- frames = 65 536 x 4096 / N.  Each kernel alone: median of 20 launches after 3 (HIP
+    events on the launch stream); every sync offset and every payload byte of the timed output checked.
+    Algorithmic bytes as SURVEY 8(d): demod B_in M N + D C mu / 8 per packet; sync B_in (Lc + W - 1) + 8."""
+    out = {"roofline_demod_by_N": {}, "roofline_sync_by_N": {}}
+    for N in (1024, 2048, 8192):
+        frames = max(64, args.frames * 4096 // N)
+        S = N + N // 8
+        stride = (17 * S + 320 + 63) // 64 * 64                  # chirp + 12 symbols + the largest gap, rounded up
+        eng, cfg, big, payload, gaps = build_workload(args, 0, N=N, frames=frames, stride=stride)
+        exp = torch.arange(frames, device=dev, dtype=torch.int64) * stride + gaps + cfg.chirp_length
+        starts = torch.empty((frames,), dtype=torch.int64, device=dev)
+        bits = torch.empty((frames, eng.bytes_per_frame), dtype=torch.uint8, device=dev)
+        ms_sync = _event_ms(lambda: eng.sync_frames(big, frames, stride, WIN_LO, WIN_LO + args.window, out_starts=starts), reps)
+        ms_dem = _event_ms(lambda: eng.demod_frames(big, starts, out_bits=bits, split=False), reps)
+        ok_sync, ok_bits = bool(torch.equal(starts, exp)), bool(torch.equal(bits, payload))
+        by_d = frames * (4 * cfg.M * N + eng.bytes_per_frame)
+        by_s = frames * (4 * (cfg.chirp_length + args.window - 1) + 8)
+        common = {"frames_per_launch": frames, "samples_per_launch": frames * stride, "timing": f"median of {reps} launches after 3 warm-ups"}
+        out["roofline_demod_by_N"][f"N{N}"] = dict(common, kernel=f"demod_kernel<{N // 2},f32,MODE_QPSK> ({N // 16} threads per packet)", bound="hbm",
+                                                  achieved=by_d / ms_dem / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", frac=by_d / ms_dem / 1e6 / HBM_PEAK_GBS,
+                                                  algorithmic_bytes_per_launch=by_d, avg_launch_ms=ms_dem, payload_recovered=ok_bits)
+        out["roofline_sync_by_N"][f"N{N}"] = dict(common, kernel="corr_kernel (plan chosen by the context for this N)", bound="hbm",
+                                                 achieved=by_s / ms_sync / 1e6, peak=HBM_PEAK_GBS, unit="GB/s", frac=by_s / ms_sync / 1e6 / HBM_PEAK_GBS,
+                                                 algorithmic_bytes_per_launch=by_s, avg_launch_ms=ms_sync, sync_offsets_exact=ok_sync)
+        del big, payload, gaps, starts, bits, exp
+        eng.close()
+        torch.cuda.empty_cache()
+    return out
+
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: fp64 vector (= matrix) peak at 2.4 GHz
+
+
+def power_roofline(dev_index, fn, t_launch_s, F, lib_sha16, seconds=2.0):
+    """What actually bounds the dominant kernel: the package power cap.  `fn` (one launch of demod_kernel over
+    the headline batch) is repeated ALONE for `seconds` while the amdgpu hwmon node is sampled -> measured_w and
+    measured_uJ_per_packet of THIS run; the cap is read from the same node.  The model beside it is the energy budget of
+    tools/energy_model.py -- resident-grid power x time + sum over instruction classes of count x energy per operation +
+    HBM bytes x energy per byte -- evaluated at this run's launch time from the committed microbenchmark prices
+    (profiles/r03_energy_budget.json) and the committed instruction mix of the kernel (profiles/instruction_mix_current.json,
+    used only if it was collected on the sources the loaded library was built from)."""
+    import importlib.util
+    ps = PowerSampler(dev_index)
+    cap_w = None
+    try:
+        if ps.path:
+            cap_w = int(open(os.path.join(os.path.dirname(ps.path), "power1_cap")).read()) * 1e-6
+    except Exception:
+        cap_w = None
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    n = 0
+    with ps:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize(); n += 10
+        dt = time.perf_counter() - t0
+    w = float(np.median(ps.samples[len(ps.samples) // 2:])) if ps.samples else None
+    out = {"what": "the dominant kernel is bound by the package power cap, not by bytes or issue slots (DESIGN 8.0): time = energy per launch / (cap - resident power)",
+           "cap_w": cap_w, "measured_w": w, "kernel_alone_ms_per_launch": dt / n * 1e3, "launches_sampled": n,
+           "measured_uJ_per_packet": (w * dt / n / F * 1e6) if w else None,
+           "resident_w": None, "model_uJ_per_packet": None, "fp64_flop_per_launch": None, "fp64_tflops": None, "fp64_frac_of_78.6": None}
+    try:
+        spec = importlib.util.spec_from_file_location("gf3_energy_model", os.path.join(ROOT, "tools", "energy_model.py"))
+        em = importlib.util.module_from_spec(spec); spec.loader.exec_module(em)
+        eb = json.load(open(os.path.join(ROOT, "profiles", "r03_energy_budget.json")))
+        mixf = json.load(open(os.path.join(ROOT, "profiles", "instruction_mix_current.json")))
+        resident, e, st = em.slopes(eb)
+        out["resident_w"] = resident
+        out["prices_source"] = "profiles/r03_energy_budget.json (tools/ubench/energy_budget.py: slopes of package power over issue rate; streaming reads)"
+        if mixf.get("source_sha16") != lib_sha16:
+            out["model_note"] = f"profiles/instruction_mix_current.json was collected on sources {mixf.get('source_sha16')}, the loaded library is {lib_sha16}: no model"
+            return out
+        mix = next(v for k, v in mixf["kernels"].items() if k.startswith("demod_kernel<2048, 1, false, 2") and f"grid={F * 256}" in k)
+        nbytes = F * 200700
+        t_s = dt / n
+        _, lo = em.budget(mix, t_s, nbytes, resident, e, st, False)
+        _, hi = em.budget(mix, t_s, nbytes, resident, e, st, True)
+        flop = 64.0 * (2 * mix["SQ_INSTS_VALU_FMA_F64"] + mix["SQ_INSTS_VALU_ADD_F64"] + mix["SQ_INSTS_VALU_MUL_F64"] + mix["SQ_INSTS_VALU_TRANS_F64"])
+        out.update({"model_uJ_per_packet": [lo / F * 1e6, hi / F * 1e6],
+                    "model_over_measured": [lo / (w * t_s), hi / (w * t_s)] if w else None,
+                    "model_source": "tools/energy_model.py on profiles/instruction_mix_current.json (SQ_INSTS_* passes of this command, same source_sha16) "
+                                    "x the committed prices; the bracket is structured ... random operand bits",
+                    "fp64_flop_per_launch": flop, "fp64_tflops": flop / t_launch_s / 1e12,
+                    "fp64_frac_of_78.6": flop / t_launch_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                    "model_ms_per_launch_at_cap": [(x - resident * t_s) / (cap_w - resident) * 1e3 for x in (lo, hi)] if cap_w else None,
+                    "model_ms_note": "modelled dynamic energy of a launch / (cap - resident power): the launch time the cap allows"})
+    except Exception as ex:                                      # (missing committed files: the measured half stands alone)
+        out["model_note"] = f"model not evaluated: {type(ex).__name__}: {ex}"
+    return out
 
 
 _POOL_P = None
@@ -289,6 +392,19 @@ def final_system_test_leg(reps=20, warm=3, cpu=True):
            "bits": int(len(bits)), "bits_sha256_equal_reference": hashlib.sha256(bits.astype(np.uint8).tobytes()).hexdigest() == str(g["sha256_bits"]),
            "ber_vs_source": repr(ber), "ber_string_equal_reference": repr(ber) == str(g["ber_str"]),
            "reference_as_written_s": 20.3, "reference_note": "OFDM.py unmodified, 1 thread, measured in the build container (BASELINE.md section 2), not on this host"}
+    # the demodulation stage alone, HIP events on the launch stream: one packet per workgroup (3 workgroups x 220 symbols)
+    # against the two-phase form the library picks for this geometry (pilot sums, estimate, data symbols over the chip)
+    eng = rx._engine(wav.dtype)
+    x = eng._samples(wav)
+    starts = (eng.sync_stream(x) + 2)[:-1]
+    want = ("Hs", "He", "slope")
+    o1, o2 = eng.demod_frames(x, starts, want=want, split=False), eng.demod_frames(x, starts, want=want)
+    out["demod_frames"] = {"plan": eng.demod_plan(int(starts.numel())),
+                           "one_launch_ms": _event_ms(lambda: eng.demod_frames(x, starts, want=want, split=False), reps, warm),
+                           "as_dispatched_ms": _event_ms(lambda: eng.demod_frames(x, starts, want=want), reps, warm),
+                           "bits_equal": bool(torch.equal(o1["bits"], o2["bits"])),
+                           "Hs_He_slope_bit_identical": all(bool(torch.equal(o1[k], o2[k])) for k in want),
+                           "timing": f"HIP events, median of {reps} launches after {warm}"}
     if cpu:
         from oracle import gf3_oracle as orc                         # the CPU baseline of this leg: the restatement on this host
         try:
@@ -568,6 +684,7 @@ def main():
                     help="N=1 only: run the N>1 code path (chunked launches, per-chunk all-gather on a side stream) "
                          "through a one-rank RCCL group; a rehearsal of the multi-GPU path, not the headline number")
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 rFFT / soft-demap roofline legs (N=1)")
+    ap.add_argument("--no-by-n", action="store_true", help="skip the legs that price the fused kernels at N = 1024, 2048, 8192 (N=1)")
     ap.add_argument("--no-stream", action="store_true", help="skip the config-3 stream-sync roofline leg (N=1)")
     ap.add_argument("--no-pcm16", action="store_true", help="skip the leg that repeats the step on int16-stored samples (N=1)")
     ap.add_argument("--no-final-system-test", action="store_true", help="skip the leg that runs the reference's own recording through the drop-in class (N=1)")
@@ -612,12 +729,13 @@ def main():
         cut into `chunks` pieces whose packed bits are all-gathered on a side stream as soon as they exist
         (chunks = 1: the literal single all-gather after the kernels)."""
 
-        def __init__(self, chunks):
+        def __init__(self, chunks, gather=True):
             self.chunks = chunks if (multi and F % chunks == 0) else 1
             self.Fc = F // self.chunks
             self.bits = torch.empty((F, eng.bytes_per_frame), dtype=torch.uint8, device=dev)
-            self.gathered = torch.empty((F * world, eng.bytes_per_frame), dtype=torch.uint8, device=dev) if multi else None
-            self.og = gd.OverlappedGather(self.gathered, F, self.chunks) if multi else None
+            # gather=False: the same launches with the collective REMOVED (what the exchange step costs is the difference)
+            self.gathered = torch.empty((F * world, eng.bytes_per_frame), dtype=torch.uint8, device=dev) if (multi and gather) else None
+            self.og = gd.OverlappedGather(self.gathered, F, self.chunks) if (multi and gather) else None
             self.starts_all = torch.empty((F,), dtype=torch.int64, device=dev)
             self.starts_c = torch.empty((self.chunks, self.Fc), dtype=torch.int64, device=dev)   # per-chunk sync results (chunk-relative)
             self.s_sync = torch.cuda.Stream() if multi else None      # chunked path: sync kernels run ahead on their own stream
@@ -653,16 +771,19 @@ def main():
                     if ev and c == 0: ev[3].record()
                     eng.demod_frames(big[c * Fc:(c + 1) * Fc], self.starts_c[c], out_bits=self.bits[c * Fc:(c + 1) * Fc])
                     if ev and c == 0: ev[2].record()
-                    self.og.chunk_done(c, self.bits[c * Fc:(c + 1) * Fc])
+                    if self.og is not None:
+                        self.og.chunk_done(c, self.bits[c * Fc:(c + 1) * Fc])
             main.wait_stream(self.s_dem2)
             main.wait_stream(self.s_sync)
             torch.add(self.starts_c, self.chunk_base, out=self.starts_all.view(chunks, Fc))
-            self.og.finish()
+            if self.og is not None:
+                self.og.finish()
             return self.starts_all
 
         def timed(self, warmup, steps):
             """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides;
-            returns (seconds = max over ranks, per-step event sets)."""
+            returns (seconds = max over ranks, per-step event sets); self.t_local = this rank's own seconds, taken
+            before the closing barrier."""
             for _ in range(warmup):
                 self.step()
             evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
@@ -672,6 +793,7 @@ def main():
             for k in range(steps):
                 self.step(evs[k])
             torch.cuda.synchronize()
+            self.t_local = time.perf_counter() - t0
             gd.barrier()
             return gd.max_over_ranks(time.perf_counter() - t0, dev), evs
 
@@ -684,7 +806,7 @@ def main():
                 bit_errors = int(np.unpackbits(x.cpu().numpy()).sum())
             sync_ok = bool(torch.equal(self.starts_all, exp_starts))
             gather_ok = None
-            if multi:
+            if multi and self.og is not None:
                 import torch.distributed as tdist
                 mine = gd.cyclic_frame_index(rank, world, F, self.chunks).to(dev)
                 gather_ok = bool(torch.equal(self.gathered[mine], self.bits))
@@ -717,9 +839,10 @@ def main():
 
     # sustained package power: the same step repeated for ~2 s after the timed region (the hwmon sensor averages
     # over a window far longer than a 20-step run), median of the second half of the samples
-    power_w, sustained = None, None
-    if not args.no_power:
-        n_probe = int(2.0 / (dt / args.steps)) + 1            # dt is the max over ranks: the same count everywhere
+    def sustained_probe(r, seconds, ms_step):
+        """`r.step` repeated for ~`seconds` inside the same bracket as the timed region (barrier + synchronize on both
+        sides, maximum over ranks), rank 0 sampling its package power: (record, watts or None)"""
+        n_probe = int(seconds / (ms_step * 1e-3)) + 1           # ms_step is the max over ranks: the same count everywhere
         power = PowerSampler(local) if rank == 0 else None
         if power is not None:
             power.__enter__()
@@ -727,31 +850,69 @@ def main():
         torch.cuda.synchronize()
         t_probe = time.perf_counter()
         for _ in range(n_probe):                               # every rank steps (the N>1 step holds a collective)
-            step()
+            r.step()
         torch.cuda.synchronize()
         gd.barrier()
         t_probe = gd.max_over_ranks(time.perf_counter() - t_probe, dev)
-        # the same step over a window a hundred times longer than a 20-step timed region (same bracket: barrier +
-        # synchronize on both sides, maximum over ranks): a second reading of `value`, not a replacement for it
-        sustained = {"steps": n_probe, "seconds": t_probe, "ms_per_step": t_probe / n_probe * 1e3,
-                     "value": world * n_samples * n_probe / t_probe, "unit": "samples/s"}
+        rec = {"steps": n_probe, "seconds": t_probe, "ms_per_step": t_probe / n_probe * 1e3,
+               "value": world * n_samples * n_probe / t_probe, "unit": "samples/s"}
+        w = None
         if power is not None:
             power.__exit__()
             if power.samples:
-                power_w = float(np.median(power.samples[len(power.samples) // 2:]))
+                w = float(np.median(power.samples[len(power.samples) // 2:]))
         gd.barrier()
+        return rec, w
+
+    power_w, sustained = None, None
+    if not args.no_power:
+        # the same step over a window a hundred times longer than a 20-step timed region: a second reading of `value`,
+        # not a replacement for it
+        sustained, power_w = sustained_probe(run, 2.0, dt / args.steps * 1e3)
 
     # N>1: the same batch once more with the literal single all-gather of the north_star (one collective per step,
-    # issued after the kernels, nothing overlapped), reported beside the chunked result
-    single = None
-    if multi and run.chunks != 1:
+    # issued after the kernels, nothing overlapped), and -- so that one scaling run says what the exchange step costs --
+    # both forms again with the collective REMOVED.  Every hot kernel alone holds the package at its power cap (DESIGN
+    # 8.0), so RCCL's copy kernels under the next chunk's compute are paid for in watts and CUs: each variant carries
+    # rank 0's sustained package power beside its time, and the gather's cost is given per rank (max and min over ranks
+    # of that rank's own seconds with the collective minus without).
+    single = no_gather = gather_cost = None
+    if multi:
+        t_chunked_local = run.t_local
+
+        def variant(chunks_v, gather):
+            rv = Run(chunks_v, gather)
+            dtv, _ = rv.timed(min(args.warmup, 2), args.steps)
+            bev, sov, gov = rv.verify()
+            rec = {"chunks": rv.chunks, "collective": bool(gather), "ms_per_step": dtv / args.steps * 1e3,
+                   "value": world * n_samples * args.steps / dtv, "unit": "samples/s", "bit_errors": bev, "sync_exact": sov, "gather_exact": gov}
+            if not args.no_power:
+                sus, w = sustained_probe(rv, 1.5, dtv / args.steps * 1e3)
+                rec.update(sustained_ms_per_step=sus["ms_per_step"], package_power_w_rank0=w)
+            t_loc = rv.t_local
+            del rv
+            return rec, t_loc
+
+        def per_rank_cost(t_with, t_without):
+            c = gd.gather_floats((t_with - t_without) / args.steps * 1e3, dev)
+            return {"max_over_ranks": max(c), "min_over_ranks": min(c), "per_rank": c}
+
+        chunks_main = run.chunks
         del run.gathered, run.og
-        run1 = Run(1)
-        dt1, _ = run1.timed(min(args.warmup, 2), args.steps)
-        be1, so1, go1 = run1.verify()
-        single = {"chunks": 1, "ms_per_step": dt1 / args.steps * 1e3, "value": world * n_samples * args.steps / dt1,
-                  "unit": "samples/s", "bit_errors": be1, "sync_exact": so1, "gather_exact": go1}
-        del run1
+        run.og = None
+        no_gather, t_ng = variant(chunks_main, False)
+        gather_cost = {"chunked_ms": per_rank_cost(t_chunked_local, t_ng),
+                       "what": "this rank's seconds per step with the collective minus the same launches without it; "
+                               "chunked: per-chunk all-gathers on a side stream under the next chunk's kernels"}
+        if chunks_main != 1:
+            single, t_single = variant(1, True)
+            ng1, t_ng1 = variant(1, False)
+            no_gather["single_launch_form"] = ng1
+            gather_cost["single_ms"] = per_rank_cost(t_single, t_ng1)
+        if power_w is not None:
+            gather_cost["package_power_w_rank0"] = {"chunked": power_w, "no_gather": no_gather.get("package_power_w_rank0"),
+                                                    "single": (single or {}).get("package_power_w_rank0"),
+                                                    "no_gather_single": no_gather.get("single_launch_form", {}).get("package_power_w_rank0")}
 
     t_sync = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])) * 1e-3
     t_demod = float(np.mean([(e[3] if multi else e[1]).elapsed_time(e[2]) for e in evs])) * 1e-3
@@ -762,22 +923,35 @@ def main():
     ach = bytes_demod / t_demod / 1e9
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/profile_round.sh ->
     # tools/collect_profiles.py -> profiles/traffic_current.json): a constant read from a file, NOT measured by this run
-    traffic, pmc = None, {}
+    # -- and only if it was collected on the sources the loaded library was built from (the file carries their hash)
+    from gf3_audio_modem_amd import _lib
+    lib_ver, lib_src16 = _lib.build_id()
+    traffic, pmc, traffic_note = None, {}, None
     tfile = os.path.join(ROOT, "profiles", "traffic_current.json")
     if os.path.exists(tfile):
         try:
             pmc = json.load(open(tfile))
+            if pmc.get("source_sha16") != lib_src16:
+                traffic_note = (f"profiles/traffic_current.json was collected on sources {pmc.get('source_sha16')}, the loaded library is "
+                                f"{lib_src16}: not quoted (rerun tools/profile_round.sh + tools/collect_profiles.py)")
+                pmc = {}
             traffic = pmc.get("demod_kernel_bytes_per_launch_at_F", {}).get(str(Fl))   # same launch size only
         except Exception:
             traffic, pmc = None, {}
     extra = {}
+    power_obj = None
     if world == 1 and not multi:
+        if not args.no_power:
+            st_all = run.starts_all
+            power_obj = power_roofline(local, lambda: eng.demod_frames(big, st_all, out_bits=run.bits), t_demod, F, lib_src16)
         del run.bits
         if not args.no_pcm16:
             extra.update(pcm16_leg(args, cfg, big, payload))
         if not args.no_config5:
             extra.update(demod_16qam_roofline(dev, args))
             extra.update(config5_rooflines(dev))
+        if not args.no_by_n:
+            extra.update(by_N_rooflines(dev, args))
         if not args.no_stream:
             extra.update(stream_sync_roofline(dev, pmc=pmc, h2d=not args.no_h2d))
         if not args.no_final_system_test:
@@ -785,8 +959,7 @@ def main():
         extra["hbm_copy_measured"] = measured_copy_bandwidth(dev)
 
     if rank == 0:
-        from gf3_audio_modem_amd import _lib
-        ver, src = _lib.build_id()
+        ver, src = lib_ver, lib_src16
         total_frames = F * world
         if multi and world > 1:
             workload = (f"BASELINE config 4: {total_frames} frames of the config-2 geometry (N=4096 CP=512 P=2 D=8 QPSK, "
@@ -809,7 +982,7 @@ def main():
             "frames_checked": total_frames, "frames_checked_note": "every rank compares its own frames with their payload; the counts are summed over ranks" if multi else None,
             "sync_exact": sync_ok,
             "gather_exact": gather_ok, "ranks_in_group": (torch.distributed.get_world_size() if multi else 1),
-            "single_gather": single,
+            "single_gather": single, "no_gather": no_gather, "gather_cost": gather_cost,
             "sustained_2s": sustained,
             "collective": ({"backend": torch.distributed.get_backend(), "library_version": rccl_version(),
                             "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"),
@@ -819,8 +992,11 @@ def main():
             "library": {"version": ver, "source_sha16": src},
             "roofline": {"kernel": "demod_kernel<2048,f32,MODE_QPSK>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/traffic_current.json (FETCH_SIZE + WRITE_SIZE passes of this command under rocprofv3, "
-                                           "gfx950-corrected; a committed constant, not measured in this run)" if traffic else None,
+                         "traffic_source": ("profiles/traffic_current.json (FETCH_SIZE + WRITE_SIZE passes of this command under rocprofv3, "
+                                            "gfx950-corrected; a committed constant collected on these sources, not measured in this run)" if traffic else traffic_note),
+                         "bound_note": "`bound: hbm` is the contract's roofline (algorithmic bytes / launch time / 8 TB/s); what sets the launch time "
+                                       "is the package power cap: see `power`",
+                         "power": power_obj,
                          "algorithmic_bytes_per_launch": bytes_demod, "avg_launch_ms": t_demod * 1e3,
                          "package_power_w_sustained": power_w,
                          "energy_nJ_per_sample": (power_w * dt / args.steps / (world * n_samples) * 1e9 * world) if power_w else None},

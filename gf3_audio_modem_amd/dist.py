@@ -125,6 +125,16 @@ def max_over_ranks(x: float, device) -> float:
     return float(t.item())
 
 
+def gather_floats(x: float, device):
+    """[x of rank 0, x of rank 1, ...] on every rank (one small all-gather; [x] without a process group)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(x)]
+    t = torch.tensor([x], dtype=torch.float64, device=device)
+    out = torch.empty(dist.get_world_size(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, t)
+    return [float(v) for v in out.cpu()]
+
+
 def spawn_ranks(cmd, n, port=None, env=None, relay=None, poll_s=0.2, grace_s=10.0):
     """Start `cmd` (an argv list) n times as FRESH processes, one per rank, with the torchrun environment
     (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT) and wait for all of them.

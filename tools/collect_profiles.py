@@ -3,10 +3,15 @@
 
     python tools/collect_profiles.py --tag r02
 
-Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu --no-power`),
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace of `python3 bench.py --no-cpu --no-power`: the --stats
+summary recomputed PER (kernel, grid) from the trace, because one kernel name is launched at several sizes by the bench's
+legs and a pooled mean cannot be compared with any one leg's figure),
 profiles/<tag>_bench.json (the bench line of the same run set), profiles/<tag>_pmc.json (HBM bytes per launch from the
 FETCH_SIZE / WRITE_SIZE passes for every kernel of the bench; issue / wait / LDS shares and the clock of the hot
-kernels from the SQ and GRBM passes) and profiles/traffic_current.json, which bench.py reads for `roofline.traffic`.
+kernels from the SQ and GRBM passes), profiles/<tag>_instruction_mix.json (SQ_INSTS_* by class for the two hot kernels) and
+the two files bench.py reads -- profiles/traffic_current.json (`roofline.traffic`) and profiles/instruction_mix_current.json
+(`roofline.power`'s model) -- both STAMPED with the source_sha16 of the library the passes ran on; bench.py quotes them
+only when the library it has loaded carries the same stamp.
 
 Counter handling follows MI355X_MICROARCH.md (HBM / rocprofv3 section): separate --pmc passes; values are KB;
 on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced streaming read, so both counters are calibrated in
@@ -51,14 +56,52 @@ def counters(sub):
     return out
 
 
+def kernel_stats_per_grid(dst):
+    """rocprofv3's --stats table, one row per (kernel name, grid size) instead of one per name"""
+    rows = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(SRC, "trace", "**", "*_kernel_trace.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+                rows[(r["Kernel_Name"], grid, int(r["Workgroup_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    total = sum(sum(v) for v in rows.values()) or 1
+    with open(dst, "w", newline="") as fh:
+        w = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(["Name", "GridThreads", "WorkgroupThreads", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for (name, grid, wg), v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+            mean = sum(v) / len(v)
+            sd = (sum((x - mean) ** 2 for x in v) / len(v)) ** 0.5
+            w.writerow([name, grid, wg, len(v), sum(v), round(mean, 3), round(100.0 * sum(v) / total, 2), min(v), max(v), round(sd, 3)])
+
+
+def instruction_mix(tag, sha16):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for sub in ("mixa", "mixb"):
+        for f in glob.glob(os.path.join(SRC, sub, "**", "*_counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                if k.startswith(("demod_kernel", "corr_kernel")):
+                    acc[f"{k} grid={int(row['Grid_Size'])}"][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    if not acc:
+        return
+    out = {"_comment": "rocprofv3 --pmc passes (two, 8 SQ counters each) of `python3 bench.py --steps 2 --warmup 1 --no-cpu --no-power` (hot-path "
+                       "legs only): wave-instructions per launch by class, mean over the launches of the run; tools/profile_round.sh",
+           "source_sha16": sha16,
+           "kernels": {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())}}
+    json.dump(out, open(os.path.join(DST, f"{tag}_instruction_mix.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(DST, "instruction_mix_current.json"), "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r03")
+    ap.add_argument("--tag", default="r04")
     args = ap.parse_args()
     os.makedirs(DST, exist_ok=True)
-    shutil.copy(newest("trace/**/*_kernel_stats.csv"), os.path.join(DST, f"{args.tag}_kernel_stats.csv"))
+    kernel_stats_per_grid(os.path.join(DST, f"{args.tag}_kernel_stats.csv"))
     bench = json.loads(open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1])
     json.dump(bench, open(os.path.join(DST, f"{args.tag}_bench.json"), "w"), indent=1)
+    sha16 = bench["library"]["source_sha16"]
+    instruction_mix(args.tag, sha16)
 
     fetch, write, sq, grbm = counters("fetch"), counters("write"), counters("sq"), counters("grbm")
     big = 16777216                                            # 65 536 workgroups of 256 threads
@@ -66,9 +109,9 @@ def main():
     cal_f = fetch[("rfft_kernel<2048, 1>", big)]["FETCH_SIZE"][0] * 1024 / cal_read
     cal_w = write[("rfft_kernel<2048, 1>", big)]["WRITE_SIZE"][0] * 1024 / cal_write
     F = bench["config"]["frames_per_gpu"]
-    algo = {"demod_kernel<2048, 1, false, 2>": bench["roofline"]["algorithmic_bytes_per_launch"],
+    algo = {"demod_kernel<2048, 1, false, 2, 0>": bench["roofline"]["algorithmic_bytes_per_launch"],
             "corr_kernel<1024, 1>": bench["roofline_sync"]["algorithmic_bytes_per_launch"]}
-    for k, leg in (("demod_kernel<2048, 1, false, 1>", "roofline_demod_16qam"), ("soft_demap_bin_kernel<3, 3>", "roofline_soft_demap")):
+    for k, leg in (("demod_kernel<2048, 1, false, 1, 0>", "roofline_demod_16qam"), ("soft_demap_bin_kernel<3, 3>", "roofline_soft_demap")):
         if leg in bench:
             algo[k] = bench[leg]["algorithmic_bytes_per_launch"]
     for N, leg in bench.get("roofline_rfft", {}).items():
@@ -109,8 +152,8 @@ def main():
            "calibration": {"fetch_reported_over_actual": cal_f, "write_reported_over_actual": cal_w},
            "hbm_traffic_per_launch": traffic, "sq_shares": shares}
     json.dump(out, open(os.path.join(DST, f"{args.tag}_pmc.json"), "w"), indent=1)
-    d = traffic[f"demod_kernel<2048, 1, false, 2> grid={big}"]
-    cur = {"_comment": f"see {args.tag}_pmc.json", "calibration": out["calibration"],
+    d = traffic[f"demod_kernel<2048, 1, false, 2, 0> grid={big}"]
+    cur = {"_comment": f"see {args.tag}_pmc.json", "source_sha16": sha16, "calibration": out["calibration"],
            "demod_kernel_bytes_per_launch_at_F": {str(F): d["hbm_bytes"]}}
     # one screened gf3_sync_stream call on the config-3 stream = one launch of each of these kernels (plus two scans and the
     # suppression walk, which are noise): VALU wave-instructions (SQ pass) and HBM bytes (FETCH / WRITE passes) per call

@@ -85,7 +85,9 @@ def main():
     ap.add_argument("--md", action="store_true", help="markdown table")
     args = ap.parse_args()
     eb = json.load(open(P("r03_energy_budget.json")))
-    mix = json.load(open(P("r03_instruction_mix.json")))["kernels"]
+    mixfile = P("instruction_mix_current.json") if os.path.exists(P("instruction_mix_current.json")) else P("r03_instruction_mix.json")
+    mix = json.load(open(mixfile))["kernels"]
+    key = lambda prefix, grid: next(k for k in mix if k.startswith(prefix) and k.endswith(f"grid={grid}"))
     kp = json.load(open(P("r03_kernel_power.json")))
     tr = json.load(open(P("traffic_current.json")))
     resident, e, st = slopes(eb)
@@ -94,8 +96,8 @@ def main():
     F = 65536
     demod_bytes = list(tr["demod_kernel_bytes_per_launch_at_F"].values())[0]
     corr_bytes = F * (4 * (23040 + 320 - 1) + 8)                  # algorithmic = measured to 0.5 % (profiles/r03_pmc.json)
-    for kname, mkey, pkey, nbytes in (("demod_kernel<2048,f32,MODE_QPSK>", "demod_kernel<2048, 1, false, 2> grid=16777216", "demod_kernel", demod_bytes),
-                                      ("corr_kernel<1024,f32>", "corr_kernel<1024, 1> grid=8388608", "corr_kernel", corr_bytes)):
+    for kname, mkey, pkey, nbytes in (("demod_kernel<2048,f32,MODE_QPSK>", key("demod_kernel<2048, 1, false, 2", 16777216), "demod_kernel", demod_bytes),
+                                      ("corr_kernel<1024,f32>", key("corr_kernel<1024, 1>", 8388608), "corr_kernel", corr_bytes)):
         t_s, p_w = kp[pkey]["ms_per_launch"] * 1e-3, kp[pkey]["package_power_w"]
         measured = p_w * t_s
         lo_rows, lo = budget(mix[mkey], t_s, nbytes, resident, e, st, False)
