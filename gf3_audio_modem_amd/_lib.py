@@ -30,6 +30,7 @@ _SIGS = {
     "gf3_ctx_create": (C.c_int, [C.POINTER(Gf3Config), C.POINTER(C.c_void_p)]),
     "gf3_ctx_destroy": (None, [C.c_void_p]),
     "gf3_last_error": (C.c_char_p, [C.c_void_p]),
+    "gf3_clear_runtime_error": (C.c_int, []),
     "gf3_debug_set_stamps": (None, [C.c_void_p, C.c_void_p]),
     "gf3_bytes_per_frame": (C.c_int32, [C.c_void_p]),
     "gf3_sync_max_window": (C.c_int32, [C.c_void_p]),

@@ -324,6 +324,7 @@ static int build_screen_plan(gf3_ctx* c) {
 }
 
 extern "C" const char* gf3_last_error(const gf3_ctx*) { return g_err; }
+extern "C" int gf3_clear_runtime_error(void) { return (int)hipGetLastError(); }
 
 extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     if (!cfg || !out) return fail(nullptr, GF3_EINVAL, "null argument");

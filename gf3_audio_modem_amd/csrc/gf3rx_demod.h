@@ -75,7 +75,9 @@ GF3_DEV int scan_table(cplx e, const double* cre, const double* cim, int M) {
 // literal scan; everywhere else the per-axis choice IS the argmin over the grid, with a margin five orders above the
 // error of tp (one Newton step on v_rcp_f64: ~1e-14 relative).  (Beyond the outermost levels tp may be flagged although
 // the edge level is certain: a spurious, harmless visit of the literal scan.)  The flag is formed by the caller from the
-// two axes' `off` in one comparison: clear <=> max(|offI|, |offQ|) < 1/2 - 1e-9 (NaN compares false).
+// two axes' `off` in one comparison: clear <=> max(|offI|, |offQ|) < 1/2 - 1e-9.  (A NaN on BOTH axes compares false;
+// fmax drops a NaN that sits on one axis only -- which cannot happen here: tp comes from the two parts of one complex
+// product ep = X conj(g), and a non-finite X or g makes both parts non-finite.)
 GF3_DEV uint32_t uni_axis(double tp, int n, unsigned long long pack, double& off) {
     off = __builtin_amdgcn_fract(tp) - 0.5;                                // |off| -> 1/2 at a boundary (the caller tests both axes at once)
     int r = (int)tp;

@@ -7,15 +7,22 @@
 // ... and the diagnostics of the calling thread's last gf3_sync_stream / gf3_sync_stream_ex (gf3_sync_stream_info)
 static thread_local int64_t g_last_info[4] = {0, 0, 0, 0};
 // Where a call reads its few result words back to: 256 bytes of PINNED host memory per calling thread (allocated on the
-// thread's first call, never freed: a copy into pageable memory goes through the runtime's staging path, which costs a call
-// tens of microseconds).  nullptr if the allocation fails -- the caller then copies into a local variable as before.
+// thread's first call and released when the thread ends -- a pool that is recreated per job does not accumulate pinned
+// pages; a copy into pageable memory goes through the runtime's staging path, which costs a call tens of microseconds).
+// nullptr if the allocation fails -- the caller then copies into a local variable as before.
+struct ReadbackPage {
+    void* p = nullptr;
+    bool tried = false;
+    ~ReadbackPage() { if (p) { (void)hipHostFree(p); p = nullptr; } }   // (a failure at process teardown is of no consequence)
+};
 static void* readback_buffer() {
-    static thread_local void* p = nullptr;
-    static thread_local bool tried = false;
-    if (!tried) { tried = true; if (hipHostMalloc(&p, 256, hipHostMallocPortable) != hipSuccess) { p = nullptr; (void)hipGetLastError(); } }
-    return p;
+    static thread_local ReadbackPage page;
+    if (!page.tried) {
+        page.tried = true;
+        if (hipHostMalloc(&page.p, 256, hipHostMallocPortable) != hipSuccess) { page.p = nullptr; (void)hipGetLastError(); }
+    }
+    return page.p;
 }
-
 
 // ============================================================================
 // stream-mode peak picking on the full correlation P (OFDM.py:359-370)
@@ -514,7 +521,9 @@ extern "C" int gf3_sync_chunk(const gf3_ctx* c, const void* d_buf, int64_t n, in
                               double* d_run_max, int64_t* d_idx, double* d_val3, int64_t cap, int64_t* n_listed,
                               double* h_piece_max, void* d_work, void* stream) {
     DeviceGuard dg(c);
-    if (!c || !d_buf || !d_run_max || !d_idx || !d_val3 || !n_listed || !d_work || n < 3 || cap < 0)
+    // (cap == 0 with no list buffers is a legitimate call: the caller's list is full, the piece then reports how many
+    //  lags it WOULD keep through GF3_ERANGE, or nothing when it keeps none)
+    if (!c || !d_buf || !d_run_max || !n_listed || !d_work || n < 3 || cap < 0 || (cap > 0 && (!d_idx || !d_val3)))
         return fail(c, GF3_EINVAL, "gf3_sync_chunk: bad argument");
     const StreamWs w = stream_ws(c, n);
     if (lag_lo < 1 || lag_hi > w.plen - 1 || lag_lo > lag_hi)

@@ -424,8 +424,9 @@ class Engine:
         host array.  Pieces overlap by Lc + one packet, so no chirp and no packet is cut.
 
         samples: 1-D numpy array or CPU torch tensor (a pinned tensor is copied from directly; pageable memory is pinned
-        in place for the duration of the call, or, if that is refused, staged through pinned buffers by a host copy per
-        piece).  chunk_samples: new samples per piece (raised to
+        in place for the duration of the call, or, if that is refused, staged through two pinned buffers by a host copy
+        per piece that a background thread makes two pieces ahead of the kernels: under piece c's kernels and piece c+1's
+        DMA, piece c+2 is being staged).  chunk_samples: new samples per piece (raised to
         two packets if smaller).  Returns dict(peaks int64 [n_det] (device), bits uint8 [n_det - 1, bytes_per_frame]
         (device, packed), info).  Raises ValueError where the reference fails (fewer than two detections; a packet that
         runs past the end of the stream)."""
@@ -454,6 +455,10 @@ class Engine:
                 registered = int(torch.cuda.cudart().cudaHostRegister(x.data_ptr(), n * x.element_size(), 0)) == 0
             except Exception:
                 registered = False
+            if not registered:
+                # a refused registration (a read-only mapping, the locked-memory limit) leaves the runtime's sticky error
+                # set; cleared here, or the next launch check of the staging path would report it as its own
+                self.lib.gf3_clear_runtime_error()
         try:
             return self._receive_host(x, x.is_pinned() or registered, registered, chunk_samples, list_cap, t_start)
         finally:
@@ -491,7 +496,8 @@ class Engine:
             res["ev_copied"] = [torch.cuda.Event() for _ in res["bufs"]]
             if not pinned_in:
                 from concurrent.futures import ThreadPoolExecutor
-                res["pool"] = ThreadPoolExecutor(4)
+                res["pool"] = ThreadPoolExecutor(4)                # the four slices of one staging copy
+                res["stager"] = ThreadPoolExecutor(1)              # the staging copy of a piece, off the calling thread
             self._tls.ingest = res
         copier, bufs, stage, ev_copied = res["copier"], res["bufs"], res["stage"], res["ev_copied"]
         idx_all, val_all, work, peaks_dev, dwork, rows = res["idx_all"], res["val_all"], res["work"], res["peaks_dev"], res["dwork"], res["rows"]
@@ -502,11 +508,27 @@ class Engine:
         n_listed = 0
         BIG = (1 << 62)
         info = dict(chunks=nchunks, chunk_samples=H, overlap_samples=carry, pinned_input=bool(pinned_in), pinned_in_place=bool(registered), h2d_bytes=0,
-                    second_look_chunks=0, second_look_packets=0, provisional_detections_dropped=0)
+                    second_look_chunks=0, second_look_packets=0, provisional_detections_dropped=0, full_list_pieces=0)
 
         def geometry(c):
             q = pieces[c]
             return q["lo"], q["hi"], q["lo"] - q["base"], q["base"], q["g_lo"], q["g_hi"]
+
+        staged = {}                                               # piece -> future of its host-side staging copy
+
+        def stage_piece(c):
+            """pageable source, registration refused: piece c's new samples -> pinned staging buffer c % 2 (a host copy by
+            four threads), once the DMA that last read that buffer has finished.  Runs on the stager thread, TWO pieces
+            ahead of the kernels: under piece c - 2's kernels and piece c - 1's DMA."""
+            b = c % 2
+            lo_s, hi_s = c * H, min(n, (c + 1) * H)
+            src, dst, m = x[lo_s:hi_s], stage[b], hi_s - lo_s
+            ev_copied[b].synchronize()                            # the copy that last read this staging buffer is done
+            if m >= (1 << 22):                                     # four host threads: 24 GB/s on the GPU box against 4 GB/s for one
+                q = -(-m // 4)
+                list(res["pool"].map(lambda k: dst[k * q: min(m, (k + 1) * q)].copy_(src[k * q: min(m, (k + 1) * q)]), range(4)))
+            else:
+                dst[:m].copy_(src)
 
         def issue_copy(c):
             """host -> dev of piece c's new samples on the copy stream (after `ev_order` of the main stream)"""
@@ -514,18 +536,14 @@ class Engine:
             lo_s, hi_s = c * H, min(n, (c + 1) * H)
             src = x[lo_s:hi_s]
             if stage is not None:
-                ev_copied[b].synchronize()                        # the copy that last read this staging buffer is done
-                m, dst = hi_s - lo_s, stage[b]
-                if m >= (1 << 22):                                 # four host threads: 24 GB/s on the GPU box against 4 GB/s for one
-                    q = -(-m // 4)
-                    list(res["pool"].map(lambda k: dst[k * q: min(m, (k + 1) * q)].copy_(src[k * q: min(m, (k + 1) * q)]), range(4)))
-                else:
-                    dst[:m].copy_(src)
-                src = dst[:m]
+                staged.pop(c).result()                            # (staged while the previous piece's kernels ran)
+                src = stage[b][: hi_s - lo_s]
             with torch.cuda.stream(copier):
                 bufs[b][carry: carry + (hi_s - lo_s)].copy_(src, non_blocking=True)
                 ev_copied[b].record(copier)
             info["h2d_bytes"] += (hi_s - lo_s) * x.element_size()
+            if stage is not None and c + 2 < nchunks:             # the staging buffer is free again once this DMA is done
+                staged[c + 2] = res["stager"].submit(stage_piece, c + 2)
 
         def sync_piece(buf, n_buf, lag_lo, lag_hi, base, idx_t, val_t, cap):
             """-> (entries listed, or -(entries wanted) - 1 when they do not fit; the piece's own maximum)"""
@@ -544,6 +562,9 @@ class Engine:
             return peaks_dev[: cnt.value].cpu().numpy()
 
         info["setup_seconds"] = time.perf_counter() - t_start    # (pinned staging, device buffers, workspace: cached by torch after the first call)
+        if stage is not None:
+            for c0 in range(min(2, nchunks)):
+                staged[c0] = res["stager"].submit(stage_piece, c0)
         issue_copy(0)
         for c in range(nchunks):
             b = c % 2
@@ -556,9 +577,12 @@ class Engine:
                 ev_order = torch.cuda.Event()
                 ev_order.record(main)                              # the other buffer is free once this point is reached
                 copier.wait_event(ev_order)
-                issue_copy(c + 1)                                  # runs under this piece's kernels
+                issue_copy(c + 1)                                  # its DMA runs under this piece's kernels
             buf = bufs[b][carry - ce: carry + (hi_s - lo_s)]
-            got, pmax = sync_piece(buf, buf.numel(), g_lo - base, g_hi - base, base, idx_all[n_listed:], val_all[n_listed:], cap_list - n_listed)
+            room = cap_list - n_listed                             # (a full list: the piece can only report that it overflows, or keep nothing)
+            info["full_list_pieces"] += int(room == 0)
+            got, pmax = sync_piece(buf, buf.numel(), g_lo - base, g_hi - base, base, idx_all[n_listed:] if room else None,
+                                   val_all[n_listed:] if room else None, room)
             if got < 0:
                 # no positive maximum yet (leading silence), or one so small that most lags of this piece stay above 0.4 x
                 # it (leading noise): nothing is kept of the piece but its own maximum, which at the end decides whether it
@@ -583,6 +607,7 @@ class Engine:
                 next_row += len(ready)
 
         info["pieces_seconds"] = time.perf_counter() - t_start - info["setup_seconds"]
+        info["listed"] = n_listed                                 # lags kept over the pieces (a superset of what the final rule can accept)
 
         # ---- the end of the stream: the maximum is final
         def piece_on_device(c):
@@ -592,7 +617,7 @@ class Engine:
             info["h2d_bytes"] += buf.numel() * x.element_size()
             return buf, base, g_lo, g_hi
 
-        extra = {}
+        extra, scratch = {}, None
         M = float(run_max[0].item())
         for c, pmax in overflow:
             if np.isfinite(M) and M > 0.0 and pmax < cfg.thresh * M * (1.0 - 1e-6):
@@ -600,9 +625,10 @@ class Engine:
                 continue                                           # no lag of that piece can pass thresh x (final maximum): nothing to look at
             buf, base, g_lo, g_hi = piece_on_device(c)
             k = g_hi - g_lo
-            it, vt = self._new((k,), torch.int64), self._new((k, 3), torch.float64)
-            got, _ = sync_piece(buf, buf.numel(), g_lo - base, g_hi - base, base, it, vt, k)
-            extra[c] = (it[:got], vt[:got])
+            if scratch is None or scratch[0].numel() < k:          # one scratch pair for every piece looked at again
+                scratch = (self._new((k,), torch.int64), self._new((k, 3), torch.float64))
+            got, _ = sync_piece(buf, buf.numel(), g_lo - base, g_hi - base, base, scratch[0], scratch[1], k)
+            extra[c] = (scratch[0][:got].clone(), scratch[1][:got].clone())   # (what is kept is what was listed, not k x 32 B)
             info["second_look_chunks"] += 1
         if overflow:
             parts_i, parts_v = [], []

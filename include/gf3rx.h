@@ -91,6 +91,10 @@ int gf3_ctx_create(const gf3_config *cfg, gf3_ctx **out);
 void gf3_ctx_destroy(gf3_ctx *ctx);
 /* message of the CALLING THREAD's last failed call (the argument is ignored: nothing is stored in a context) */
 const char *gf3_last_error(const gf3_ctx *ctx);
+/* Returns and CLEARS the HIP runtime's sticky last error of the calling thread (0 = none).  For callers that made a HIP
+ * call of their own that may fail by design -- e.g. pinning a read-only mapping with hipHostRegister before handing it
+ * to the ingest path -- so that the refusal is not reported by the next unrelated launch check. */
+int gf3_clear_runtime_error(void);
 
 /* diagnostics: in a library built with -DGF3_STAMPS, gf3_demod_frames writes eight s_memtime
  * stamps per frame into this device buffer ([F][8] uint64); a no-op in the product build */

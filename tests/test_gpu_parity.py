@@ -1392,3 +1392,42 @@ def test_unpack_decode_kernel_matches_numpy(C, mu, D):
     addr = pageable.ctypes.data + (-pageable.ctypes.data) % 16
     rc = eng.lib.gf3_unpack_bits(eng._h, ctypes.c_void_p(packed.data_ptr()), F, None, 0, ctypes.c_void_p(addr), None)
     assert rc == -1 and b"pinned" in eng.lib.gf3_last_error(None)
+
+
+def test_receive_host_list_exactly_full_and_refused_registration(tmp_path):
+    """ (i) a kept-lag list that is EXACTLY full when a piece begins: the piece is offered no room (cap 0, no
+    buffers) and is either empty or overflows into the second look -- for every capacity from 1 to the number of lags
+    the stream keeps, the detections and bits are the oracle's; (ii) a source the runtime refuses to pin in place (a
+    read-only file mapping): the refusal is cleared, the staging path (host copies two pieces ahead, on a background
+    thread) gives the same result, and the next unrelated launch sees no stale error."""
+    g = load("g1_n1024_qpsk")
+    p = params_of(g)
+    r, payload = _crafted_stream(p, 50)
+    ref = orc.receive(r, p)
+    want_peaks = np.flatnonzero(ref["zeros"])
+    eng = engine_for(p)
+    base = eng.receive_host(r, chunk_samples=1)
+    listed = base["info"]["listed"]
+    assert 4 <= listed <= 400, base["info"]
+    full = 0
+    for cap in range(1, listed + 1):
+        out = eng.receive_host(r, chunk_samples=1, list_cap=cap)
+        full += out["info"]["full_list_pieces"]
+        assert np.array_equal(out["peaks"].cpu().numpy(), want_peaks), (cap, out["info"])
+        assert torch.equal(out["bits"], base["bits"]), cap
+    assert full >= 1                                                    # some capacity left a piece no room at all
+    assert np.array_equal(eng.unpack_bits(base["bits"]).cpu().numpy(), ref["bits"])
+    # (ii)
+    path = tmp_path / "stream.f64"
+    r.tofile(path)
+    ro = np.memmap(path, dtype=np.float64, mode="r")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                                 # (torch warns about wrapping a non-writable array)
+        out = eng.receive_host(ro, chunk_samples=1, pin_in_place=True)
+    assert np.array_equal(out["peaks"].cpu().numpy(), want_peaks) and torch.equal(out["bits"], base["bits"])
+    assert eng.lib.gf3_clear_runtime_error() == 0                       # nothing left behind, whichever way the registration went
+    assert torch.equal(eng.sync_stream(torch.from_numpy(r).cuda()), out["peaks"])
+    staged = eng.receive_host(r, chunk_samples=1, pin_in_place=False)   # the fallback itself, forced: many pieces, pipeline two ahead
+    assert staged["info"]["chunks"] >= 4 and not staged["info"]["pinned_input"]
+    assert torch.equal(staged["peaks"], out["peaks"]) and torch.equal(staged["bits"], base["bits"])
