@@ -111,12 +111,17 @@ enum { MODE_FULL = 0, MODE_SCAN = 1, MODE_QPSK = 2 };
 template <int NC, int MODE> struct DemodOcc {
     static constexpr int WPS = (MODE == MODE_QPSK && NC <= 2048) ? GF3_DEMOD_WPS : 2;
     static constexpr bool MAG_LDS = (MODE != MODE_QPSK);
+    // N = 8192 (NC = 4096, 512 threads): the register file allows one workgroup per CU whatever the LDS does, and two
+    // 64 KB buffers fit beside the decision ring (148 KB of 160) -- one barrier per exchange instead of two, with no other
+    // workgroup on the CU to run under a barrier.  Four passes end in the second buffer and the next transform starts in
+    // the first, so the buffers need not be flipped (rfft_regs passes flip = 0 for the unfused sizes).
+    static constexpr bool PP_SIZE = FftGeom<NC>::PINGPONG || NC == 4096;
 #if GF3_ABL >= 2
-    static constexpr bool PP = FftGeom<NC>::PINGPONG && WPS <= 2;
+    static constexpr bool PP = PP_SIZE && WPS <= 2;
 #else
-    static constexpr bool PP = FftGeom<NC>::PINGPONG && WPS <= 2 && !MAG_LDS;
+    static constexpr bool PP = PP_SIZE && WPS <= 2 && !MAG_LDS;
 #endif
-    static constexpr int LDS_ELEMS = PP ? FftGeom<NC>::LDS_ELEMS : FftGeom<NC>::LDS_ELEMS_INPLACE;
+    static constexpr int LDS_ELEMS = PP ? 2 * NC : FftGeom<NC>::LDS_ELEMS_INPLACE;
     static constexpr int MAG_ELEMS = MAG_LDS ? NC : 0;             // double2 (a0, da) per slot per thread: 8 * NC/8
 };
 
@@ -543,7 +548,8 @@ inline int demod_ring(const gf3_ctx* c) {
 // FFT buffer on is overlaid by Hs, He of the fit range during the channel-estimate stage (which may need more).
 inline size_t demod_lds_bytes(const gf3_ctx* c, bool lean = false) {
     const bool inplace = !lean || (GF3_DEMOD_WPS > 2 && c->NC <= 2048);
-    const size_t fft = inplace ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : fft_lds_bytes(c->NC);
+    const bool pp_size = c->NC == 1024 || c->NC == 2048 || c->NC == 4096;        // == DemodOcc::PP_SIZE
+    const size_t fft = (inplace || !pp_size) ? (size_t)(c->NC + c->NC / 8) * sizeof(cplx) : (size_t)2 * c->NC * sizeof(cplx);
     const size_t mags = lean ? 0 : (size_t)c->NC * sizeof(double2);
     const size_t tail = fft + (size_t)((demod_ring(c) * c->cfg.C + 15) & ~15) + mags;
     const size_t fit = (size_t)2 * (c->fit_hi - c->fit_lo) * sizeof(cplx);

@@ -815,9 +815,10 @@ def test_stream_screen_error_bound_holds(case, kernel):
 
 @pytest.mark.parametrize("kernel", ["band_limited", "general"])
 def test_stream_screen_is_reproducible(kernel):
-    """The screening pass, run ten times over an 80 M-sample stream (20 000 blocks): the same lags, block maxima and
-    bounds bit for bit.  (A bound read from LDS before every wave had written its share of it came out different for
-    one block in about half a million.)"""
+    """The screening pass twice over an 80 M-sample stream (20 000 blocks): the same lags, block maxima and bounds bit
+    for bit -- a determinism check (a fixed reduction order, no atomics on values), not a race detector: what rules a race
+    out is the kernel's structure (the block's bound is evaluated after the barrier, by every wave for itself from the
+    completed LDS rows: gf3rx_screen.h) and the error-bound tests, which a wrong bound fails."""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("config3_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "config3.py"))
     c3 = importlib.util.module_from_spec(spec); spec.loader.exec_module(c3)
@@ -825,15 +826,15 @@ def test_stream_screen_is_reproducible(kernel):
     r, _ = c3.make_stream(eng, channel, 1024)
     eng.sync_stream_mode(3 if kernel == "general" else 2)
     ref = None
-    for _ in range(10):
+    for _ in range(2):
         p32, bmax, berr, hop = eng.debug_stream_screen(r)
         assert bool(torch.isfinite(berr).all())
         if ref is None:
             ref = (p32.clone(), bmax.clone(), berr.clone())
         else:
             assert torch.equal(berr, ref[2]) and torch.equal(bmax, ref[1]) and torch.equal(p32, ref[0])
-    peaks = [eng.sync_stream(r).cpu().numpy() for _ in range(4)]
-    assert all(np.array_equal(peaks[0], q) for q in peaks[1:]) and len(peaks[0]) == 1025
+    peaks = [eng.sync_stream(r).cpu().numpy() for _ in range(2)]
+    assert np.array_equal(peaks[0], peaks[1]) and len(peaks[0]) == 1025
     eng.close()
 
 
