@@ -231,9 +231,13 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         }
     } else if constexpr (STAGE == STAGE_DATA) {
         // the estimate stage's Hs, He (true scale, divided by the known symbols): the same doubles the one-launch kernel
-        // holds in registers at this point, so u, a0, da below come out bit for bit the same
+        // holds in registers at this point, so u, a0, da below come out bit for bit the same.  (He only feeds the
+        // magnitude model: the sign mode never looks at it.)
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) { Hs[s2] = a.Hs[f * K + bin_of(s2) - 1]; He[s2] = a.He[f * K + bin_of(s2) - 1]; }
+        for (int s2 = 0; s2 < 8; ++s2) {
+            Hs[s2] = a.Hs[f * K + bin_of(s2) - 1];
+            if constexpr (MODE != MODE_QPSK) He[s2] = a.He[f * K + bin_of(s2) - 1]; else He[s2] = cmk(0.0, 0.0);
+        }
     } else {
         for (int side = 0; side < 2; ++side) {
             cplx sum[8];
