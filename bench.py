@@ -463,6 +463,44 @@ def pcm16_leg(args, cfg, big, payload, steps=20, warm=3):
                               "payload_bytes_wrong": errs, "sample_bytes_per_step": 2 * n_samples}}
 
 
+def screened_sync_leg(args, eng, big, payload, exp_starts, steps=20, warm=3):
+    """The headline step with the OPT-IN screened frames sync in place of the all-fp64 one (gf3_sync_frames_ex mode 1,
+    gf3rx_fscreen.h): every search window in fp32 with a proven bound, the decision taken where the bound decides it, the
+    all-fp64 kernel on the windows it does not (none on this clean batch).  The indices are the fp64 kernel's by
+    construction and are checked here against the expected offsets; the demodulation is the same all-fp64 kernel.  A
+    secondary figure: `value` stays the all-fp64 step."""
+    F = big.shape[0]
+    starts = torch.empty((F,), dtype=torch.int64, device=big.device)
+    bits = torch.empty((F, eng.bytes_per_frame), dtype=torch.uint8, device=big.device)
+    work = eng.sync_frames_workspace(F)
+
+    def sync():
+        eng.sync_frames(big, F, args.stride, WIN_LO, WIN_LO + args.window, out_starts=starts, screened=True, work=work)
+
+    def step():
+        sync()
+        eng.demod_frames(big, starts, out_bits=bits)
+    ms_sync = _event_ms(sync, steps, warm)
+    for _ in range(warm):
+        step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    for _ in range(steps):
+        step()
+    ev[1].record()
+    torch.cuda.synchronize()
+    ms = ev[0].elapsed_time(ev[1]) / steps
+    n_samples = F * args.stride
+    return {"screened_sync": {"workload": "the headline step with gf3_sync_frames_ex mode 1 (fp32 screen with a proven bound per window + fp64 kernel on "
+                                          "unresolved windows) in front of the same all-fp64 demodulation",
+                              "dtype": "f32 screen + f64 decisions", "ms_per_step": ms, "value": n_samples / (ms * 1e-3), "unit": "samples/s",
+                              "steps": steps, "sync_ms": ms_sync, "sync_timing": f"median of {steps} launches after {warm} (HIP events)",
+                              "windows_sent_to_fp64": int(work[:4].view(torch.int32).item()), "windows": F,
+                              "sync_exact": bool(torch.equal(starts, exp_starts)), "payload_bytes_wrong": int((bits != payload).sum().item()),
+                              "note": "a secondary figure: `value` and `roofline_sync` are the all-fp64 sync"}}
+
+
 def _event_ms(fn, reps=20, warm=3):
     """SURVEY 8(d) protocol for the secondary legs: MEDIAN HIP-event time of `fn` (one launch on the current stream)
     over `reps` >= 20 launches after `warm` = 3 untimed ones, in ms"""
@@ -686,6 +724,7 @@ def main():
     ap.add_argument("--no-config5", action="store_true", help="skip the config-5 rFFT / soft-demap roofline legs (N=1)")
     ap.add_argument("--no-by-n", action="store_true", help="skip the legs that price the fused kernels at N = 1024, 2048, 8192 (N=1)")
     ap.add_argument("--no-stream", action="store_true", help="skip the config-3 stream-sync roofline leg (N=1)")
+    ap.add_argument("--no-screened-sync", action="store_true", help="skip the leg that repeats the step with the opt-in screened frames sync (N=1)")
     ap.add_argument("--no-pcm16", action="store_true", help="skip the leg that repeats the step on int16-stored samples (N=1)")
     ap.add_argument("--no-final-system-test", action="store_true", help="skip the leg that runs the reference's own recording through the drop-in class (N=1)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-ingest (pinned, chunked H2D + stream receive) leg (N=1)")
@@ -945,6 +984,8 @@ def main():
             st_all = run.starts_all
             power_obj = power_roofline(local, lambda: eng.demod_frames(big, st_all, out_bits=run.bits), t_demod, F, lib_src16)
         del run.bits
+        if not args.no_screened_sync:
+            extra.update(screened_sync_leg(args, eng, big, payload, exp_starts))
         if not args.no_pcm16:
             extra.update(pcm16_leg(args, cfg, big, payload))
         if not args.no_config5:

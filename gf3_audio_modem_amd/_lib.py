@@ -48,6 +48,11 @@ _SIGS = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gf3_sync_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gf3_sync_frames_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int64]),
+    "gf3_sync_frames_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "gf3_debug_frames_screen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gf3_sync_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, c_i64_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "gf3_sync_stream_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, c_i64_p,

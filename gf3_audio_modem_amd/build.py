@@ -27,7 +27,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 # translation units, slowest first (the pool starts them in this order)
 UNITS = ["gf3rx_demod_full", "gf3rx_dsplit_full", "gf3rx_demod_scan", "gf3rx_dsplit_scan", "gf3rx_demod_qpsk", "gf3rx_dsplit_qpsk",
-         "gf3rx_screen", "gf3rx_corr", "gf3rx_demod_split",
+         "gf3rx_screen", "gf3rx_corr", "gf3rx_demod_split", "gf3rx_fscreen",
          "gf3rx_fft", "gf3rx_sync", "gf3rx_abi"]
 SRC = [os.path.join(CSRC, u + ".hip") for u in UNITS]
 STAMP_SRC = os.path.join(CSRC, "gf3rx_stamp.cpp")

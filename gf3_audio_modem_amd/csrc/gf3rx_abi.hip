@@ -2,6 +2,7 @@
 // but the stream sync (gf3rx_sync.hip); the small stand-alone kernels (demappers, zero forcing, Schmidl-Cox) live here too.
 // See DESIGN.md for the layout and gf3rx_host.h for the map of translation units.
 #include "gf3rx_demod.h"
+#include "gf3rx_fscreen.h"
 
 // Message of the calling thread's last failure.  One buffer per host thread, none in the context: concurrent calls
 // on one context (different streams, different threads) cannot overwrite each other's text, and a failing call
@@ -323,6 +324,45 @@ static int build_screen_plan(gf3_ctx* c) {
     return GF3_OK;
 }
 
+// Screening plan of the frames-mode sync (gf3rx_fscreen.h): fp32 spectra of the chirp partitions for 2048-sample transforms
+// in the kernel's slot order, max |H_q| per partition for the bound.  Computed on the host in fp64, rounded once.
+static int build_fscreen_plan(gf3_ctx* c, int wmax) {
+    constexpr int NC = GF3_FS_NC, N = 2 * GF3_FS_NC;
+    auto& fp = c->fscr;
+    fp.ok = false;
+    if (wmax < 3 || wmax > N / 2) return GF3_OK;          // (wider windows: the all-fp64 kernel only)
+    const int Lp = N - wmax + 1, Q = (c->Lc + Lp - 1) / Lp;
+    if (Q > 256) return GF3_OK;
+    fp.Q = Q; fp.Lp = Lp; fp.wmax = wmax;
+    std::vector<float> Hs((size_t)Q * 8 * 64 * 4), H0N((size_t)Q * 2), Hinf(Q);
+    for (int q = 0; q < Q; ++q) {
+        std::vector<double> re(N, 0.0), im(N, 0.0);
+        for (int k = 0; k < Lp && q * Lp + k < c->Lc; ++k) re[k] = c->chirp[(size_t)q * Lp + k];
+        host_fft(re, im);
+        double mx = 0.0;
+        for (int k = 0; k <= NC; ++k) mx = fmax(mx, hypot(re[k], im[k]));
+        Hinf[q] = (float)(mx * (1.0 + 1e-6));
+        H0N[2 * q] = (float)re[0]; H0N[2 * q + 1] = (float)re[NC];
+        for (int r = 0; r < 8; ++r)
+            for (int t = 0; t < 64; ++t) {
+                const int k = (t == 0 && r == 0) ? NC / 2 : t + 64 * r;
+                float* o = &Hs[(((size_t)q * 8 + r) * 64 + t) * 4];
+                o[0] = (float)re[k]; o[1] = (float)im[k]; o[2] = (float)re[NC - k]; o[3] = (float)im[NC - k];
+            }
+    }
+    std::vector<float> tw(2 * NC), twn(2 * 64);
+    const long double PI2 = 6.283185307179586476925286766559005768L;
+    for (int m = 0; m < NC; ++m) { const long double a = -PI2 * m / NC; tw[2 * m] = (float)cosl(a); tw[2 * m + 1] = (float)sinl(a); }
+    for (int k = 0; k < 64; ++k) { const long double a = -PI2 * k / N; twn[2 * k] = (float)cosl(a); twn[2 * k + 1] = (float)sinl(a); }
+    HIPCHK(c, upload((float**)&fp.d_tw, tw.data(), tw.size()));
+    HIPCHK(c, upload((float**)&fp.d_twn, twn.data(), twn.size()));
+    HIPCHK(c, upload((float**)&fp.d_Hs, Hs.data(), Hs.size()));
+    HIPCHK(c, upload(&fp.d_H0N, H0N.data(), H0N.size()));
+    HIPCHK(c, upload(&fp.d_Hinf, Hinf.data(), Hinf.size()));
+    fp.ok = true;
+    return GF3_OK;
+}
+
 extern "C" const char* gf3_last_error(const gf3_ctx*) { return g_err; }
 extern "C" int gf3_clear_runtime_error(void) { return (int)hipGetLastError(); }
 
@@ -528,6 +568,7 @@ extern "C" int gf3_ctx_create(const gf3_config* cfg, gf3_ctx** out) {
     if (rc == GF3_OK) rc = build_plan(c, &c->stream_plan, NCs, ts, NCs);
     if (rc == GF3_OK) rc = build_known_time(c);
     if (rc == GF3_OK) rc = build_screen_plan(c);
+    if (rc == GF3_OK) rc = build_fscreen_plan(c, wmax);
     if (rc != GF3_OK) { gf3_ctx_destroy(c); return rc; }
     *out = c;
     return GF3_OK;
@@ -538,7 +579,8 @@ extern "C" void gf3_ctx_destroy(gf3_ctx* c) {
     DeviceGuard dg(c);
     void* ptrs[] = {c->d_tw_x[0], c->d_twn_x[0], c->d_tw_x[1], c->d_twn_x[1], c->d_tw, c->d_twn, c->d_known, c->d_pos, c->d_clab, c->d_cre, c->d_cim,
                     c->frames_plan.d_Hq, c->stream_plan.d_Hq, c->d_idx_of_label, c->d_chirp, c->d_chirp_t, c->d_known_time,
-                    c->scr.d_tw, c->scr.d_twn, c->scr.d_Hs, c->scr.d_H0N, c->scr.d_Hinf, c->scr.d_Hb, c->scr.d_ecoef};
+                    c->scr.d_tw, c->scr.d_twn, c->scr.d_Hs, c->scr.d_H0N, c->scr.d_Hinf, c->scr.d_Hb, c->scr.d_ecoef,
+                    c->fscr.d_tw, c->fscr.d_twn, c->fscr.d_Hs, c->fscr.d_H0N, c->fscr.d_Hinf};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete c;
 }
@@ -740,11 +782,19 @@ extern "C" int gf3_schmidl_cox(gf3_ctx* c, const void* d_r, int64_t n, int64_t s
 }
 
 
-extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64_t F, int64_t stride,
-                               int32_t win_lo, int32_t win_hi, int64_t* d_starts, double* d_peak, void* stream) {
+extern "C" int64_t gf3_sync_frames_workspace_bytes(const gf3_ctx* c, int64_t F) {
+    if (!c || F < 0) return 0;
+    return (int64_t)((size_t)F * sizeof(int) + 64);           // [count | pad | unresolved window numbers]
+}
+
+// mode 0: all fp64 (corr_kernel on every window).  mode 1: fp32 screen with a proven bound per window (gf3rx_fscreen.h);
+// the windows it cannot decide are listed and corr_kernel runs on those.  The starts are the same either way.
+static int sync_frames_impl(gf3_ctx* c, const void* d_in, int64_t n_in, int64_t F, int64_t stride, int32_t win_lo, int32_t win_hi,
+                            int64_t* d_starts, double* d_peak, int32_t mode, void* d_work, float* dbg_y32, float* dbg_err, int* dbg_cls,
+                            bool screen_only, void* stream) {
     DeviceGuard dg(c);
     if (c && F == 0) return GF3_OK;
-    if (!c || !d_in || !d_starts || F < 0) return fail(c, GF3_EINVAL, "gf3_sync_frames: bad argument");
+    if (!c || !d_in || !d_starts || F < 0 || mode < 0 || mode > 1) return fail(c, GF3_EINVAL, "gf3_sync_frames: bad argument");
     const int W = win_hi - win_lo;
     const CorrPlan& pl = c->frames_plan;
     if (W < 3 || W > pl.W) return fail(c, GF3_EINVAL, "gf3_sync_frames: window %d outside [3, %d]", W, pl.W);
@@ -752,8 +802,39 @@ extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64
     a.t = pl.t; a.in = d_in; a.n_in = n_in; a.dt = c->cfg.in_dtype;
     a.Hq = pl.d_Hq; a.Q = pl.Q; a.Lp = pl.Lp; a.Lc = c->Lc; a.Wmax = W;
     a.stride = stride; a.win_lo = win_lo; a.W = W; a.starts = d_starts; a.peak = d_peak; a.thresh = c->cfg.thresh;
-    HIPCHK(c, run_corr(c, pl, a, F, (hipStream_t)stream));
+    const auto& fp = c->fscr;
+    // the screen serves index-only calls within its plan's window; a caller that wants the fp64 peak VALUE gets the fp64 kernel
+    const bool screened = mode == 1 && d_work && fp.ok && W <= fp.wmax && !d_peak && F <= 0x7fffffff;
+    if (screen_only && !screened) return fail(c, GF3_EINVAL, "gf3_debug_frames_screen: no screening plan for this window (max_window %d)", fp.wmax);
+    if (!screened) {
+        HIPCHK(c, run_corr(c, pl, a, F, (hipStream_t)stream));
+        return GF3_OK;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int* count = (int*)d_work;
+    int* list = (int*)((char*)d_work + 64);
+    HIPCHK(c, hipMemsetAsync(count, 0, 64, st));
+    FScreenArgs fa{d_in, n_in, c->cfg.in_dtype, fp.d_tw, fp.d_twn, fp.d_Hs, fp.d_H0N, fp.d_Hinf, fp.Q, fp.Lp, c->Lc, W,
+                   stride, win_lo, W, (float)c->cfg.thresh, d_starts, list, count, dbg_y32, dbg_err, dbg_cls};
+    HIPCHK(c, launch_fscreen(c, fa, F, st));
+    if (screen_only) return GF3_OK;
+    a.list = list; a.count = count;
+    HIPCHK(c, run_corr(c, pl, a, F, st, true));               // (grid = the list's capacity; workgroups past its length return at once)
     return GF3_OK;
+}
+extern "C" int gf3_sync_frames(gf3_ctx* c, const void* d_in, int64_t n_in, int64_t F, int64_t stride,
+                               int32_t win_lo, int32_t win_hi, int64_t* d_starts, double* d_peak, void* stream) {
+    return sync_frames_impl(c, d_in, n_in, F, stride, win_lo, win_hi, d_starts, d_peak, 0, nullptr, nullptr, nullptr, nullptr, false, stream);
+}
+extern "C" int gf3_sync_frames_ex(gf3_ctx* c, const void* d_in, int64_t n_in, int64_t F, int64_t stride,
+                                  int32_t win_lo, int32_t win_hi, int64_t* d_starts, double* d_peak, int32_t mode, void* d_work, void* stream) {
+    return sync_frames_impl(c, d_in, n_in, F, stride, win_lo, win_hi, d_starts, d_peak, mode, d_work, nullptr, nullptr, nullptr, false, stream);
+}
+// tests: the screening pass alone -- fp32 lags [F][W], the bound per window, the verdict per window (0 resolved with a
+// detection, 1 resolved without, 2 unresolved: d_starts is then left alone), the unresolved windows in d_work
+extern "C" int gf3_debug_frames_screen(gf3_ctx* c, const void* d_in, int64_t n_in, int64_t F, int64_t stride, int32_t win_lo, int32_t win_hi,
+                                       int64_t* d_starts, float* d_y32, float* d_err, int32_t* d_cls, void* d_work, void* stream) {
+    return sync_frames_impl(c, d_in, n_in, F, stride, win_lo, win_hi, d_starts, nullptr, 1, d_work, d_y32, d_err, d_cls, true, stream);
 }
 
 static int run_demap(gf3_ctx* c, const void* d_sym, int64_t n, uint8_t* bits, uint8_t* idx, float* llr, double nv, void* stream);

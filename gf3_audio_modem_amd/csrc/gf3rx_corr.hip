@@ -15,15 +15,14 @@
 #ifndef GF3_CORR_PP
 #define GF3_CORR_PP true
 #endif
+// One search window: everything corr_kernel does for window b.
 template <int NC, int DT>
-__global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_kernel(CorrArgs a) {
-    extern __shared__ double2 smem[];
+GF3_DEV void corr_window(const CorrArgs& a, const int64_t b, double2* smem) {
     constexpr int T = NC / 8;
     constexpr bool PP = GF3_CORR_PP && FftGeom<NC>::PINGPONG;
     cplx* lds = smem;
     double* scratch = (double*)(smem + (PP ? FftGeom<NC>::LDS_ELEMS : FftGeom<NC>::LDS_ELEMS_INPLACE));
     const int tid = threadIdx.x;
-    const int64_t b = blockIdx.x;
     const int64_t s0 = b * a.stride + a.win_lo;      // absolute sample index of lag 0 of this window
     const int W = a.W;                               // lags to resolve
 
@@ -152,6 +151,19 @@ __global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_
         if (a.peak) a.peak[b] = found ? y[first] : 0.0;
     }
 }
+// LISTED: the windows are those of a device-side list (the screened sync's unresolved windows, gf3rx_fscreen.h), whose
+// length lives on the device: the grid is the list's capacity and workgroups past its length return at once (65 536 empty
+// workgroups are ~25 us; a persistent grid walking the list was tried -- the loop's invariants spill 4-36 registers of a
+// kernel that has none to spare).  The plain instantiation is the kernel it was.
+template <int NC, int DT, bool LISTED = false>
+__global__ __launch_bounds__(NC / 8, (NC <= 2048 ? GF3_CORR_WPS : 2)) void corr_kernel(CorrArgs a) {
+    extern __shared__ double2 smem[];
+    if constexpr (!LISTED) corr_window<NC, DT>(a, blockIdx.x, smem);
+    else {
+        if ((int)blockIdx.x >= *a.count) return;
+        corr_window<NC, DT>(a, a.list[blockIdx.x], smem);
+    }
+}
 
 template <int NC, int DT>
 __global__ __launch_bounds__(NC / 8, 2) void spec_kernel(OlsArgs a) {
@@ -278,17 +290,18 @@ __global__ __launch_bounds__(NC / 8, 2) void ols_kernel(OlsArgs a) {
     if (tid == 0) a.part[item] = anynan ? NAN : mx;
 }
 
-hipError_t run_corr(const gf3_ctx* c, const CorrPlan& pl, const CorrArgs& a, int64_t grid, hipStream_t st) {
+hipError_t run_corr(const gf3_ctx* c, const CorrPlan& pl, const CorrArgs& a, int64_t grid, hipStream_t st, bool listed) {
     const int NCp = pl.NC;
     const size_t lds = (GF3_CORR_PP ? fft_lds_bytes(NCp) : (size_t)(NCp + NCp / 8) * sizeof(cplx)) + 32 * sizeof(double);
     hipError_t e = hipSuccess;
 #ifdef GF3_DEV_BUILD
-    if (NCp == 1024) {
+    if (NCp == 1024 && !listed) {
         if (a.dt == DT_F64) return launch((corr_kernel<1024, DT_F64>), grid, 128, lds, st, a);
         return launch((corr_kernel<1024, DT_F32>), grid, 128, lds, st, a);
     }
 #endif
-    DISPATCH_NC(NCp, a.dt, e = launch((corr_kernel<NCC, DTC>), grid, NCC / 8, lds, st, a));
+    if (listed) { DISPATCH_NC(NCp, a.dt, e = launch((corr_kernel<NCC, DTC, true>), grid, NCC / 8, lds, st, a)); }
+    else { DISPATCH_NC(NCp, a.dt, e = launch((corr_kernel<NCC, DTC>), grid, NCC / 8, lds, st, a)); }
     return e;
 }
 

@@ -104,6 +104,7 @@ struct CorrArgs {
     int Q, Lp, Lc, Wmax;
     int64_t stride; int win_lo; int W;      // window f = chirp-start lags [f*stride + win_lo, +W)
     int64_t* starts; double* peak; double thresh;
+    const int* list; const int* count;      // LISTED launches (the screened sync's unresolved windows): window = list[blockIdx.x], blockIdx.x < *count
 };
 
 // ============================================================================
@@ -179,6 +180,9 @@ struct gf3_ctx {
     struct { bool ok = false; int Q = 0, H = 0; cf *d_tw = nullptr, *d_twn = nullptr; float4* d_Hs = nullptr;
              float *d_H0N = nullptr, *d_Hinf = nullptr;
              bool ring = false; float4* d_Hb = nullptr; float* d_ecoef = nullptr; int R_forced = 0; } scr;   // band-limited kernel (scr_ring_kernel)
+    // single-precision screening plan of the frames-mode sync (gf3rx_fscreen.h): 2048-sample transforms, partitions of 2048 - wmax + 1 taps
+    struct { bool ok = false; int Q = 0, Lp = 0, wmax = 0; cf *d_tw = nullptr, *d_twn = nullptr; float4* d_Hs = nullptr;
+             float *d_H0N = nullptr, *d_Hinf = nullptr; } fscr;
     // The ONLY field a call may write after gf3_ctx_create: the default evaluation mode of the legacy entry point
     // gf3_sync_stream (gf3_sync_stream_mode sets it; gf3_sync_stream_ex takes the mode per call and never reads it).
     // 0: by stream length (screen from GF3_SCR_MIN_SAMPLES on); 1: fp64 only; 2: screen whenever a plan exists; 3: as 2 with the general kernel
@@ -273,7 +277,10 @@ hipError_t launch_dsplit_qpsk(const gf3_ctx* c, const DemodArgs& a, int64_t grid
 hipError_t launch_dsplit_scan(const gf3_ctx* c, const DemodArgs& a, int64_t grid, hipStream_t st);
 hipError_t launch_dsplit_full(const gf3_ctx* c, const DemodArgs& a, int64_t grid, hipStream_t st);
 // gf3rx_corr.hip
-hipError_t run_corr(const gf3_ctx* c, const CorrPlan& pl, const CorrArgs& a, int64_t grid, hipStream_t st);
+hipError_t run_corr(const gf3_ctx* c, const CorrPlan& pl, const CorrArgs& a, int64_t grid, hipStream_t st, bool listed = false);
+// gf3rx_fscreen.hip: the screened frames sync (fp32 with a bound per window; unresolved windows are listed for corr_kernel)
+struct FScreenArgs;
+hipError_t launch_fscreen(const gf3_ctx* c, const FScreenArgs& a, int64_t F, hipStream_t st);
 hipError_t run_spec_ols(const CorrPlan& pl, OlsArgs a, int64_t nwin, int64_t nblk, hipStream_t st);   // spec_kernel, then ols_kernel
 // gf3rx_screen.hip
 hipError_t launch_screen(const gf3_ctx* c, ScreenArgs a, bool general, hipStream_t st);

@@ -280,9 +280,12 @@ class Engine:
             _ptr(o["slope"]), _ptr(o.get("Hest")), _ptr(o["bits"]), self._stream()))
         return o
 
-    def sync_frames(self, x, F, stride, win_lo, win_hi, want_peak=False, out_starts=None):
+    def sync_frames(self, x, F, stride, win_lo, win_hi, want_peak=False, out_starts=None, screened=False, work=None):
         """Batched windowed chirp sync: first-pilot sample index per frame (int64, -1 = none).
-        out_starts: optional preallocated int64 [F] device tensor to write into."""
+        out_starts: optional preallocated int64 [F] device tensor to write into.
+        screened: evaluate the windows in fp32 with a proven bound first (gf3_sync_frames_ex mode 1) and run the fp64
+        kernel only on the windows the bound cannot decide: the same indices.  work: optional preallocated uint8 workspace
+        (gf3_sync_frames_workspace_bytes; its first int32 then holds the number of windows that went to fp64)."""
         x = self._samples(x)
         if out_starts is not None:
             if out_starts.dtype != torch.int64 or out_starts.numel() != F or not out_starts.is_contiguous():
@@ -291,9 +294,29 @@ class Engine:
         else:
             starts = self._new((F,), torch.int64)
         peak = self._new((F,), torch.float64) if want_peak else None
-        self._check(self.lib.gf3_sync_frames(self._h, _ptr(x), x.numel(), F, stride, win_lo, win_hi,
-                                             _ptr(starts), _ptr(peak), self._stream()))
+        if screened and work is None:
+            work = self.sync_frames_workspace(F)
+        self._check(self.lib.gf3_sync_frames_ex(self._h, _ptr(x), x.numel(), F, stride, win_lo, win_hi,
+                                                _ptr(starts), _ptr(peak), 1 if screened else 0, _ptr(work) if screened else None, self._stream()))
         return (starts, peak) if want_peak else starts
+
+    def sync_frames_workspace(self, F):
+        return self._new((int(self.lib.gf3_sync_frames_workspace_bytes(self._h, F)),), torch.uint8)
+
+    def debug_frames_screen(self, x, F, stride, win_lo, win_hi):
+        """The fp32 screening pass of the frames sync alone (tests): dict(starts int64 [F] (resolved windows only), y32
+        [F, W] float32, err [F] float32 -- the bound on |y32 - exact| --, cls int32 [F] (0 resolved with a detection, 1
+        resolved without, 2 unresolved), unresolved: sorted window numbers the fp64 kernel would be run on)."""
+        x = self._samples(x)
+        W = win_hi - win_lo
+        o = dict(starts=torch.full((F,), -7, dtype=torch.int64, device=self.device), y32=self._new((F, W), torch.float32),
+                 err=self._new((F,), torch.float32), cls=self._new((F,), torch.int32))
+        work = self.sync_frames_workspace(F)
+        self._check(self.lib.gf3_debug_frames_screen(self._h, _ptr(x), x.numel(), F, stride, win_lo, win_hi, _ptr(o["starts"]),
+                                                     _ptr(o["y32"]), _ptr(o["err"]), _ptr(o["cls"]), _ptr(work), self._stream()))
+        n = int(work[:4].view(torch.int32).item())
+        o["unresolved"] = torch.sort(work[64: 64 + 4 * n].view(torch.int32)).values
+        return o
 
     def sync_stream(self, x, cap=None, want_corr=False, mode=None, want_info=False):
         """chirp_method on one stream: indices i with zeros[i] True (int64 tensor).

@@ -186,6 +186,30 @@ int gf3_sync_frames(gf3_ctx *ctx, const void *d_in, int64_t n_in,
                     int64_t *d_starts, double *d_peak_or_null, void *stream);
 
 /*
+ * The same search with an fp32 SCREEN in front (gf3rx_fscreen.h), opt-in: mode 1 evaluates every window in single
+ * precision with a proven bound on |fp32 lag - exact lag| (2048-sample transforms held by one wave each, the chirp's
+ * partition spectra multiplied in, one inverse transform) and takes the decision -- the index of the first extremum above
+ * thresh x the window's maximum -- only where the bound decides it: every lag is certainly out, certainly in, or undecided,
+ * and a window is resolved when no undecided lag precedes the first certain one.  Unresolved windows (noise at the threshold,
+ * flat tops, non-finite samples, a maximum the bound cannot tell from zero) are listed on the device and the all-fp64 kernel
+ * runs on exactly those.  No decision rests on an fp32 value the bound does not back: d_starts is what mode 0 writes.
+ *   mode    0: all fp64 (== gf3_sync_frames)   1: screened
+ *   d_work  gf3_sync_frames_workspace_bytes(ctx, F) bytes of device memory (mode 1; NULL selects mode 0); after the call its
+ *           first int32 holds the number of windows that went to the fp64 kernel
+ * Falls back to mode 0 when d_peak is asked for (an fp64 VALUE), when the window is wider than the context's max_window or
+ * than 1024 lags, and when F exceeds 2^31.
+ */
+int64_t gf3_sync_frames_workspace_bytes(const gf3_ctx *ctx, int64_t F);
+int gf3_sync_frames_ex(gf3_ctx *ctx, const void *d_in, int64_t n_in, int64_t F, int64_t stride,
+                       int32_t win_lo, int32_t win_hi, int64_t *d_starts, double *d_peak_or_null,
+                       int32_t mode, void *d_work, void *stream);
+/* tests: the screening pass alone.  d_y32 [F][W] fp32 lags, d_err [F] the bound of each window, d_cls [F] 0 resolved with a
+ * detection / 1 resolved without / 2 unresolved (d_starts[f] is then left alone); d_work as above */
+int gf3_debug_frames_screen(gf3_ctx *ctx, const void *d_in, int64_t n_in, int64_t F, int64_t stride,
+                            int32_t win_lo, int32_t win_hi, int64_t *d_starts, float *d_y32, float *d_err,
+                            int32_t *d_cls, void *d_work, void *stream);
+
+/*
  * chirp_method with full reference semantics on one contiguous stream
  * (OFDM.py:356-372): full-coverage matched filter, normalisation by the GLOBAL
  * maximum, extremum-and-threshold candidates, sequential non-max suppression

@@ -1432,3 +1432,107 @@ def test_receive_host_list_exactly_full_and_refused_registration(tmp_path):
     staged = eng.receive_host(r, chunk_samples=1, pin_in_place=False)   # the fallback itself, forced: many pieces, pipeline two ahead
     assert staged["info"]["chunks"] >= 4 and not staged["info"]["pinned_input"]
     assert torch.equal(staged["peaks"], out["peaks"]) and torch.equal(staged["bits"], base["bits"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the screened frames-mode sync (gf3_sync_frames_ex mode 1; gf3rx_fscreen.h)
+# ---------------------------------------------------------------------------------------------------------------
+def _window_lags_fp64(r, p, s0, W):
+    """y[j] = sum_k r[s0 + j + k] c[k], j < W, in fp64 (samples beyond the stream are zeros)"""
+    c = orc.chirp_replica(p)
+    seg = np.zeros(W + p.Lc - 1)
+    lo, hi = max(0, s0), min(len(r), s0 + len(seg))
+    if hi > lo:
+        seg[lo - s0: hi - s0] = r[lo:hi]
+    return np.correlate(seg, c, mode="valid")
+
+
+@pytest.mark.parametrize("N,CP,mu,dt", [(1024, 128, 2, torch.float32), (4096, 512, 2, torch.float32), (2048, 256, 6, torch.float64),
+                                        (4096, 224, 2, torch.int16), (8192, 1024, 2, torch.float32)])
+def test_screened_sync_frames_equals_fp64_and_bound_holds(N, CP, mu, dt):
+    """Every window of a batch through the fp32 screen: (i) the bound E covers |y32 - y| for every lag of every window, against
+    fp64 dot products on the host (clean windows, noisy ones, a window hanging over the end of the buffer, an empty one);
+    (ii) the screened call returns exactly the all-fp64 kernel's indices; (iii) clean windows are resolved by the screen
+    alone, and only unresolved ones reach the fp64 kernel."""
+    pts, bt = orc.qpsk_table() if mu == 2 else orc.square_qam_table(mu)
+    K = N // 2 - 1
+    known = load("g6_realrec")["known_bits"]
+    known = np.tile(known, -(-K * mu // len(known)))
+    p = orc.RxParams(N=N, CP=CP, P=2, D=2, lo=1, hi=K, const_points=pts, const_bits=bt, known_bits=known,
+                     fit_lo=min(500, K // 2), fit_hi=min(1000, K))
+    F = 8
+    rows, gaps, payload = _rows_with_gaps(p, F, seed=3 * N + mu)
+    rs = np.random.RandomState(N)
+    rows[2] += 0.05 * rs.randn(rows.shape[1])                  # a noisy window
+    rows[3] += 0.6 * rs.randn(rows.shape[1])                   # chirp near the noise: extrema everywhere around the threshold
+    rows[5] = 1e-3 * rs.randn(rows.shape[1])                   # no chirp at all
+    rows[6] = 0.0                                              # silence: the maximum is not above zero
+    rows[5, -64:] = 0.0                                        # (window 6 starts 8 samples inside row 5)
+    if dt == torch.int16:
+        q = np.round(rows * (20000.0 / np.abs(rows).max()))
+        x = torch.from_numpy(q.astype(np.int16)).cuda(); r64 = q.reshape(-1)
+    elif dt == torch.float32:
+        x = torch.from_numpy(rows.astype(np.float32)).cuda(); r64 = rows.astype(np.float32).astype(np.float64).reshape(-1)
+    else:
+        x = torch.from_numpy(rows).cuda(); r64 = rows.reshape(-1)
+    eng = engine_for(p, in_dtype=dt, max_window=320)
+    stride, lo, W = rows.shape[1], -8, 320
+    d = eng.debug_frames_screen(x, F, stride, lo, lo + W)
+    y32, err, cls = d["y32"].cpu().numpy(), d["err"].cpu().numpy(), d["cls"].cpu().numpy()
+    worst = 0.0
+    for f in range(F):
+        y = _window_lags_fp64(r64, p, f * stride + lo, W)
+        e = np.abs(y32[f].astype(np.float64) - y).max()
+        assert e <= err[f], (f, e, err[f])
+        worst = max(worst, e / err[f])
+    assert worst < 0.5, worst                                  # (the constant is generous: realised / bound stays far below 1)
+    ref = eng.sync_frames(x, F, stride, lo, lo + W)
+    scr = eng.sync_frames(x, F, stride, lo, lo + W, screened=True)
+    assert torch.equal(ref, scr)
+    clean = [0, 1, 4, 7]
+    assert all(cls[f] == 0 for f in clean), cls              # decided by the screen alone ...
+    assert np.array_equal(d["starts"].cpu().numpy()[clean], ref.cpu().numpy()[clean])   # ... to the fp64 kernel's index
+    assert cls[6] == 2, cls                                    # silence: nothing above zero, left to the fp64 kernel (-1)
+    assert int(ref[6]) == -1
+    assert np.array_equal(np.flatnonzero(cls == 2), d["unresolved"].cpu().numpy())
+    assert (cls == 2).sum() < F                                # (the screen is selective here)
+
+
+def test_screened_sync_frames_on_multipath_and_narrow_windows():
+    """The multipath fixture (echoes: several extrema above the threshold before the largest): screened == fp64 for windows
+    narrower than the plan's, starting at odd offsets, and for a window wider than the plan (the call then IS the fp64 one)."""
+    g = load("g3_n4096_16qam_gr5")
+    p = params_of(g)
+    eng = engine_for(p, max_window=400)
+    x = torch.from_numpy(g["r"]).cuda()
+    for pk in g["peaks"][:-1]:
+        s_true = int(pk) + 1 - (p.Lc - 1)
+        for lo, W in ((s_true - 150, 400), (s_true - 33, 97), (s_true - 5, 11), (s_true - 299, 300), (s_true + 3, 50)):
+            a = eng.sync_frames(x, 1, 0, lo, lo + W)
+            b = eng.sync_frames(x, 1, 0, lo, lo + W, screened=True)
+            assert torch.equal(a, b), (lo, W, a, b)
+    eng2 = engine_for(p, max_window=1400)                      # wider than the screen's transform allows: no plan, fp64 either way
+    lo = int(g["peaks"][0]) + 1 - (p.Lc - 1) - 600
+    assert torch.equal(eng2.sync_frames(x, 1, 0, lo, lo + 1400), eng2.sync_frames(x, 1, 0, lo, lo + 1400, screened=True))
+
+
+def test_screened_sync_frames_full_size_round_trip():
+    """BASELINE config-2 geometry, 4 096 distinct packets with jitter gaps: the screened sync returns every offset, none of
+    the windows needs the fp64 kernel, and the demodulated payload is exact."""
+    pts, bt = orc.qpsk_table()
+    K = 2047
+    known = np.tile(load("g6_realrec")["known_bits"], -(-K * 2 // 4096))
+    p = orc.RxParams(N=4096, CP=512, P=2, D=8, lo=1, hi=K, const_points=pts, const_bits=bt, known_bits=known)
+    eng = engine_for(p, in_dtype=torch.float32, max_window=320)
+    F, stride = 4096, 78720
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    packed = torch.randint(0, 256, (F, eng.bytes_per_frame), dtype=torch.uint8, device="cuda", generator=gen)
+    gaps = torch.randint(0, 300, (F,), dtype=torch.int64, device="cuda", generator=gen)
+    filler = np.zeros(K, dtype=complex); filler[K - 1] = (1 - 1j) / np.sqrt(2)
+    rows = eng.tx_frames(packed, filler, stride=stride, gaps=gaps, out_dtype=torch.float32)
+    work = eng.sync_frames_workspace(F)
+    starts = eng.sync_frames(rows, F, stride, -8, 312, screened=True, work=work)
+    assert torch.equal(starts, torch.arange(F, device="cuda") * stride + gaps + p.Lc)
+    assert int(work[:4].view(torch.int32).item()) == 0         # every window decided by the screen
+    assert torch.equal(eng.demod_frames(rows, starts)["bits"], packed)
+    assert torch.equal(starts, eng.sync_frames(rows, F, stride, -8, 312))
