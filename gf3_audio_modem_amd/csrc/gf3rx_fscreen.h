@@ -118,9 +118,31 @@ GF3_DEV void pf_twiddle16(pf (&v)[16], pf w) {
 
 GF3_DEV int fs_swz(int i) { return i ^ ((i >> 4) & 15); }          // XOR swizzle of the first exchange (8-byte elements)
 
-struct FsTw { pf tw2; pf tw3; };                             // pass 2: exp(-2 pi i (t & 15) / 256); pass 3: w_b^1..3, w_b = exp(-2 pi i (t + 64 b) / 1024)
-// Forward complex FFT of 1024 points in ONE wave: in v[r] = z[t + 64 r]; out Z[t + 64 q] in v[q], q = 0..15.
+struct FsTw { pf tw2; pf tw3; };                                  // pass 2: exp(-2 pi i (t & 15) / 256); pass 3: exp(-2 pi i ((t & 15) + 64 (t >> 4)) / 1024)
+#ifndef GF3_FS_PERMLANE
+#define GF3_FS_PERMLANE 1     /* 1: the second exchange runs through v_permlane32_swap / v_permlane16_swap instead of LDS */
+#endif
+// swap the upper 32 lanes of a with the lower 32 lanes of b / the odd rows (of 16 lanes) of a with the even rows of b
+GF3_DEV void pf_swap32(pf& a, pf& b) {
+    auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = pfmk(__uint_as_float(rx[0]), __uint_as_float(ry[0])); b = pfmk(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
+}
+GF3_DEV void pf_swap16(pf& a, pf& b) {
+    auto rx = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false);
+    auto ry = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false);
+    a = pfmk(__uint_as_float(rx[0]), __uint_as_float(ry[0])); b = pfmk(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
+}
+// Forward complex FFT of 1024 points in ONE wave: in v[r] = z[t + 64 r]; out (GF3_FS_PERMLANE) v[i + 4 m] =
+// Z[(t & 15) + 16 i + 64 (t >> 4) + 256 m], i, m < 4 -- fs_bin(t, s) -- else Z[t + 64 s] in v[s].
 // L: the wave's private 1024-point LDS buffer (in place: a wave's LDS instructions execute in order).
+GF3_DEV int fs_bin(int t, int s) {
+#if GF3_FS_PERMLANE
+    return (t & 15) + 16 * (s & 3) + 64 * (t >> 4) + 256 * (s >> 2);
+#else
+    return t + 64 * s;
+#endif
+}
 GF3_DEV void fs_fft1024(pf (&v)[16], pf* L, const FsTw& tw, int t) {
     pf_dft16(v);                                                   // X[m] in v[scr_perm(m)]
 #pragma unroll
@@ -134,6 +156,38 @@ GF3_DEV void fs_fft1024(pf (&v)[16], pf* L, const FsTw& tw, int t) {
     }
     pf_twiddle16(v, tw.tw2);                                       // w = exp(-2 pi i (t & 15) / 256)
     pf_dft16(v);
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+#if GF3_FS_PERMLANE
+    // Second exchange WITHOUT LDS.  Lane (row rho = t >> 4, column k = t & 15) holds, as X[m] in v[scr_perm(m)], element
+    // 256 rho + k + 16 m of the pass's output; the radix-4 butterflies of the last pass combine the four ROWS of one column.
+    // A 4 x 4 transpose of chunks of four m across the rows -- two stages of cross-row swaps, 32 instructions -- leaves lane
+    // (rho, k) with v[c + 4 i] = element 256 c + k + 16 (4 rho + i): the four inputs of butterfly j_i = k + 16 i + 64 rho.
+    // (chunk c of a lane = m in [4c, 4c + 4) = registers v[c], v[c + 4], v[c + 8], v[c + 12].)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pf_swap32(v[0 + 4 * i], v[2 + 4 * i]); pf_swap32(v[1 + 4 * i], v[3 + 4 * i]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pf_swap16(v[0 + 4 * i], v[1 + 4 * i]); pf_swap16(v[2 + 4 * i], v[3 + 4 * i]); }
+    {
+        const float c64[4] = {1.0f, 0.99518472667219688624f, 0.98078528040323044913f, 0.95694033573220886494f};      // cos(2 pi i / 64)
+        const float s64[4] = {0.0f, 0.09801714032956060199f, 0.19509032201612826785f, 0.29028467725446236764f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const pf w1 = i == 0 ? tw.tw3 : pf_cmul(tw.tw3, pfmk(c64[i], -s64[i]));   // exp(-2 pi i j_i / 1024)
+            const pf w2 = pf_cmul(w1, w1), w3 = pf_cmul(w2, w1);
+            pf a0 = v[4 * i], a1 = pf_cmul(v[4 * i + 1], w1), a2 = pf_cmul(v[4 * i + 2], w2), a3 = pf_cmul(v[4 * i + 3], w3);
+            pf_dft4(a0, a1, a2, a3);                               // outputs m = 0..3: Z[j_i + 256 m]
+            v[4 * i] = a0; v[4 * i + 1] = a1; v[4 * i + 2] = a2; v[4 * i + 3] = a3;
+        }
+        // (slot order i + 4 m, as fs_bin has it)
+        pf o[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) o[i + 4 * m] = v[4 * i + m];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) v[s2] = o[s2];
+    }
+#else
     {
         const int k = t & 15, base = (t - k) * 16 + k;
 #pragma unroll
@@ -148,7 +202,6 @@ GF3_DEV void fs_fft1024(pf (&v)[16], pf* L, const FsTw& tw, int t) {
             for (int r = 0; r < 4; ++r) x[4 * b + r] = L[t + 64 * b + 256 * r];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
             const pf w16[4] = {pfmk(1.0f, 0.0f), pfmk(c1, -s1), pfmk(h, -h), pfmk(s1, -c1)};       // exp(-2 pi i b / 16)
             const pf w1 = b == 0 ? tw.tw3 : pf_cmul(tw.tw3, w16[b]);
             const pf w2 = pf_cmul(w1, w1), w3 = pf_cmul(w2, w1);
@@ -157,6 +210,8 @@ GF3_DEV void fs_fft1024(pf (&v)[16], pf* L, const FsTw& tw, int t) {
             v[b] = a0; v[b + 4] = a1; v[b + 8] = a2; v[b + 12] = a3;   // slot q = b + 4 m
         }
     }
+#endif
+    (void)c1; (void)s1; (void)h;
 }
 
 #ifndef GF3_FS_WPS
@@ -185,7 +240,7 @@ __global__ __launch_bounds__(64, GF3_FS_WPS) void corr_screen_kernel(FScreenArgs
     const pf* twp = (const pf*)a.tw;
     FsTw tw;
     tw.tw2 = twp[(t & 15) * 4];
-    tw.tw3 = twp[t];
+    tw.tw3 = twp[fs_bin(t, 0)];
     pf wb = ((const pf*)a.twn)[t];
     auto wsplit = [&](int r) { return (t == 0 && r == 0) ? pfmk(0.0f, -1.0f) : pf_cmul(wb, pfmk(c8[r], -s8[r])); };
     auto refresh = [&]() { asm volatile("" : "+v"(tw.tw2), "+v"(tw.tw3), "+v"(wb)); };
@@ -234,19 +289,27 @@ __global__ __launch_bounds__(64, GF3_FS_WPS) void corr_screen_kernel(FScreenArgs
         //  requested after this one's multiply-adds, its latency covered by the SIMD's other wave)
         constexpr bool EARLY = GF3_FS_EARLY && DT != DT_F64;
         if (EARLY && q + 1 < a.Q) fetch(q + 1);
+        // this partition's spectrum (an L2-resident table): requested BEFORE the transform, whose LDS round trips then cover
+        // the L2 latency -- asked for next to the multiply-adds it sat, exposed, between the split's reads and the first fma
+        // (f64 samples: no registers for that; two batches after the transform)
+        const float4* Hp = a.Hs + (int64_t)q * 8 * 64;
+        float4 hq[8];
+        if constexpr (EARLY) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) hq[r] = Hp[r * 64 + t];
+        }
+        const float h0 = a.H0N[2 * q], hN = a.H0N[2 * q + 1];
         refresh();
         fs_fft1024(v, L, tw, t);
 #pragma unroll
-        for (int m = 0; m < 16; ++m) L[t + 64 * m] = v[m];                 // natural order for the packed-real split
-        // this partition's spectrum (L2-resident table), requested before the split's LDS reads
-        const float4* Hp = a.Hs + (int64_t)q * 8 * 64;
-        const float h0 = a.H0N[2 * q], hN = a.H0N[2 * q + 1];
+        for (int m = 0; m < 16; ++m) L[fs_bin(t, m)] = v[m];               // natural order for the packed-real split
         const pf z0 = L[0];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-        float4 hq[8];
+        if constexpr (!EARLY) {
 #pragma unroll
-        for (int r = 4 * half; r < 4 * half + 4; ++r) hq[r] = Hp[r * 64 + t];
+            for (int r = 4 * half; r < 4 * half + 4; ++r) hq[r] = Hp[r * 64 + t];
+        }
 #pragma unroll
         for (int r = 4 * half; r < 4 * half + 4; ++r) {
             const bool self = (t == 0 && r == 0);
@@ -288,7 +351,7 @@ __global__ __launch_bounds__(64, GF3_FS_WPS) void corr_screen_kernel(FScreenArgs
     const float inv = 0.25f / (float)NC;              // 1/NC of the inverse transform, 1/2 of each of the two splits
     float* y = (float*)L;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) L[t + 64 * m] = pfmk(v[m].x * inv, -v[m].y * inv);
+    for (int m = 0; m < 16; ++m) L[fs_bin(t, m)] = pfmk(v[m].x * inv, -v[m].y * inv);
     // ---- the window rule on bounded values
     float mx = -INFINITY;
     bool nonfinite = !(Eb < INFINITY);
