@@ -151,3 +151,81 @@ def test_gpu_host_ingest_equals_one_shot(N, F, storage, chunk_frames, snr_db, se
     one = eng.sync_stream(x, mode=1)
     assert torch.equal(one, out["peaks"]) and torch.equal(eng.demod_frames(x, (one + 2)[:-1])["bits"], out["bits"])
     eng.close()
+
+
+@pytest.mark.gpu
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(N=st.sampled_from([1024, 2048, 4096, 8192]), F=st.integers(1, 4), D=st.sampled_from([2, 5, 9, 16, 23, 40]),
+       storage=st.sampled_from(["float64", "float32", "int16"]), snr_db=st.sampled_from([60.0, 25.0, 12.0]),
+       cp_frac=st.sampled_from([1 / 32, 1 / 8, 1 / 4]), P=st.integers(1, 4), mu=st.sampled_from([2, 4, 6]),
+       lo_frac=st.floats(0, 1), hi_frac=st.floats(0, 1), seed=st.integers(0, 2 ** 31 - 1))
+def test_gpu_two_phase_demod_equals_one_launch(N, F, D, storage, snr_db, cp_frac, P, mu, lo_frac, hi_frac, seed):
+    """gf3_demod_frames_ex, two-phase form forced (pilot sums, estimate, data symbols in word-aligned chunks) against the
+    one-launch kernel over random geometries, constellations, storages and noise: Hs / He / slope bit for bit, packed bits
+    identical in the bits-only and the dump mode, equalised symbols within 1e-12 -- and the bits are the oracle's."""
+    import torch
+    from gf3_audio_modem_amd import Engine, RxConfig
+    p = _params(N, cp_frac, P, D, mu, lo_frac, hi_frac)
+    dt = getattr(torch, storage)
+    cfg = RxConfig(N=p.N, CP=p.CP, P=p.P, D=p.D, data_bins=p.data_carriers, const_points=p.const_points, const_bits=p.const_bits,
+                   known_bits=p.known_bits, in_dtype=dt, fit_lo=p.fit_lo, fit_hi=p.fit_hi, max_window=256)
+    eng = Engine(cfg)
+    rs = np.random.RandomState(seed)
+    payload = rs.randint(0, 2, F * p.D * p.C * p.mu)
+    fill = rs.choice(np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2), size=p.K - p.C)
+    filler = np.zeros(p.K, dtype=complex)
+    filler[np.delete(np.arange(1, p.K + 1), p.data_carriers - 1) - 1] = fill
+    rows = eng.tx_frames(orc.pack_bits(payload, p.D * p.C * p.mu), filler, out_dtype=torch.float64)
+    rows = rows + torch.from_numpy(rs.randn(*rows.shape)).cuda() * float(rows.std()) * 10 ** (-snr_db / 20)
+    rows = torch.round(rows * (20000.0 / float(rows.abs().max()))).to(torch.int16) if storage == "int16" else rows.to(dt)
+    starts = torch.arange(F, device="cuda") * rows.shape[1] + p.Lc
+    want = ("eq", "Hs", "He", "slope")
+    one, two = eng.demod_frames(rows, starts, want=want, split=False), eng.demod_frames(rows, starts, want=want, split=True)
+    assert torch.equal(one["bits"], two["bits"])
+    for k in ("Hs", "He", "slope"):
+        assert torch.equal(one[k], two[k]), k
+    assert float((one["eq"] - two["eq"]).abs().max()) <= 1e-12 * max(1.0, float(one["eq"].abs().max()))
+    assert torch.equal(eng.demod_frames(rows, starts, split=True)["bits"], eng.demod_frames(rows, starts, split=False)["bits"])
+    ref = orc.demod_frames(rows.cpu().numpy().astype(np.float64).reshape(-1), starts.cpu().numpy(), p)
+    assert np.array_equal(eng.unpack_bits(two["bits"]).cpu().numpy().reshape(-1), ref["bits"].reshape(-1))
+    eng.close()
+
+
+@pytest.mark.gpu
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(N=st.sampled_from([1024, 2048, 4096, 8192]), F=st.integers(1, 6), storage=st.sampled_from(["float64", "float32", "int16", "uint8"]),
+       snr_db=st.sampled_from([60.0, 20.0, 6.0, 0.0, -6.0]), cp_frac=st.sampled_from([1 / 32, 1 / 8, 1 / 4]),
+       W=st.sampled_from([16, 97, 256, 320]), seed=st.integers(0, 2 ** 31 - 1))
+def test_gpu_screened_frames_sync_equals_fp64(N, F, storage, snr_db, cp_frac, W, seed):
+    """gf3_sync_frames_ex mode 1 (fp32 screen with a proven bound, fp64 kernel on unresolved windows) returns the all-fp64
+    kernel's index for every window, from clean chirps down to chirps below the noise (where most windows are unresolved
+    and go to the fp64 kernel), on every sample storage, for windows narrower than the plan's."""
+    import torch
+    from gf3_audio_modem_amd import Engine, RxConfig
+    p = _params(N, cp_frac, 1, 2, 2, 0.0, 0.0)
+    dt = getattr(torch, storage)
+    rs = np.random.RandomState(seed)
+    cfg = RxConfig(N=p.N, CP=p.CP, P=p.P, D=p.D, data_bins=p.data_carriers, const_points=p.const_points, const_bits=p.const_bits,
+                   known_bits=p.known_bits, in_dtype=dt, fit_lo=p.fit_lo, fit_hi=p.fit_hi, max_window=320)
+    eng = Engine(cfg)
+    payload = rs.randint(0, 2, F * p.D * p.C * p.mu)
+    fill = rs.choice(np.array([1 + 1j, 1 - 1j, -1 + 1j, -1 - 1j]) / np.sqrt(2), size=p.K - p.C)
+    filler = np.zeros(p.K, dtype=complex)
+    filler[np.delete(np.arange(1, p.K + 1), p.data_carriers - 1) - 1] = fill
+    gaps = rs.randint(0, max(1, W - 12), F)
+    stride = p.frame_len + 400
+    rows = eng.tx_frames(orc.pack_bits(payload, p.D * p.C * p.mu), filler, stride=stride, gaps=gaps, out_dtype=torch.float64)
+    rows = rows + torch.from_numpy(rs.randn(*rows.shape)).cuda() * float(rows.std()) * 10 ** (-snr_db / 20)
+    if storage == "int16":
+        rows = torch.round(rows * (20000.0 / float(rows.abs().max()))).to(torch.int16)
+    elif storage == "uint8":
+        rows = (torch.round(rows * (100.0 / float(rows.abs().max()))) + 128).to(torch.uint8)
+    else:
+        rows = rows.to(dt)
+    a = eng.sync_frames(rows, F, stride, -8, W - 8)
+    work = eng.sync_frames_workspace(F)
+    b = eng.sync_frames(rows, F, stride, -8, W - 8, screened=True, work=work)
+    assert torch.equal(a, b), (a, b, int(work[:4].view(torch.int32).item()))
+    if snr_db >= 20.0:
+        assert np.array_equal(a.cpu().numpy(), np.arange(F) * stride + gaps + p.Lc)
+    eng.close()
