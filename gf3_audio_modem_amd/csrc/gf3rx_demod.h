@@ -151,9 +151,10 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
     const int K = a.K, P = a.P, D = a.D, S = a.S;
     int l_lo = 0, l_hi = D;                                               // data symbols this workgroup demodulates
     if constexpr (STAGE == STAGE_DATA) {
-        f = blockIdx.x / (unsigned)a.nchunk;
-        l_lo = (int)(blockIdx.x - (unsigned)f * (unsigned)a.nchunk) * a.Dc;
-        l_hi = min(D, l_lo + a.Dc);
+        const unsigned pk = blockIdx.x / (unsigned)a.nchunk;
+        f = pk;
+        l_lo = __builtin_amdgcn_readfirstlane((int)(blockIdx.x - pk * (unsigned)a.nchunk) * a.Dc);     // (wave-uniform: kept in scalar registers)
+        l_hi = __builtin_amdgcn_readfirstlane(min(D, l_lo + a.Dc));
     }
     const int Bs = a.C * a.mu;                                            // bits per data symbol
     uint8_t* row = a.bits + f * (int64_t)a.row_bytes;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2) {
             Hs[s2] = a.Hs[f * K + bin_of(s2) - 1];
-            if constexpr (MODE != MODE_QPSK) He[s2] = a.He[f * K + bin_of(s2) - 1]; else He[s2] = cmk(0.0, 0.0);
+            He[s2] = cmk(0.0, 0.0);                   // (the table modes fetch He slot by slot below, next to its one use)
         }
     } else {
         for (int side = 0; side < 2; ++side) {
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(NC / 8, (DemodOcc<NC, MODE>::WPS)) void demod_kerne
         const double m2 = Hs[s].x * Hs[s].x + Hs[s].y * Hs[s].y;
         const double ia = rsq_nr(m2);                                 // 1/|Hs|
         if constexpr (MODE != MODE_QPSK) {
+            if constexpr (STAGE == STAGE_DATA) He[s] = a.He[f * K + bin_of(s) - 1];
             const double e2 = He[s].x * He[s].x + He[s].y * He[s].y;
             const double ah = m2 * ia;                                // |Hs|
             a0[s] = XS * ah;

@@ -447,9 +447,10 @@ class Engine:
         host array.  Pieces overlap by Lc + one packet, so no chirp and no packet is cut.
 
         samples: 1-D numpy array or CPU torch tensor (a pinned tensor is copied from directly; pageable memory is pinned
-        in place for the duration of the call, or, if that is refused, staged through two pinned buffers by a host copy
+        in place for the duration of the call, or, if that is refused, staged through THREE pinned buffers by a host copy
         per piece that a background thread makes two pieces ahead of the kernels: under piece c's kernels and piece c+1's
-        DMA, piece c+2 is being staged).  chunk_samples: new samples per piece (raised to
+        DMA, piece c+2 is being staged -- into the buffer piece c-1 was copied from, which is idle by then, so the thread
+        makes no HIP call at all).  chunk_samples: new samples per piece (raised to
         two packets if smaller).  Returns dict(peaks int64 [n_det] (device), bits uint8 [n_det - 1, bytes_per_frame]
         (device, packed), info).  Raises ValueError where the reference fails (fewer than two detections; a packet that
         runs past the end of the stream)."""
@@ -465,7 +466,19 @@ class Engine:
         else:
             a = np.asarray(samples).reshape(-1)
             want = torch.empty(0, dtype=cfg.in_dtype).numpy().dtype
-            x = torch.from_numpy(np.ascontiguousarray(a if a.dtype == want else a.astype(want)))
+            b = np.ascontiguousarray(a if a.dtype == want else a.astype(want))
+            # Only ordinary, writable process memory is pinned in place.  A read-only array or a file mapping (np.memmap) is
+            # staged instead: registering such a range asks the driver for write access to pages the process may not write,
+            # and a registration that outlives its mapping poisons whatever is mapped there next.
+            m = b
+            while isinstance(m, np.ndarray) and not isinstance(m, np.memmap) and m.base is not None:
+                m = m.base
+            if not b.flags.writeable or not isinstance(m, np.ndarray) or isinstance(m, np.memmap):
+                pin_in_place = False
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")                    # (torch warns when it wraps a non-writable array; it is only read)
+                x = torch.from_numpy(b)
         n = x.numel()
         if n < 3:
             raise ValueError("stream too short")
@@ -487,7 +500,8 @@ class Engine:
         finally:
             if registered:
                 torch.cuda.synchronize(self.device)
-                torch.cuda.cudart().cudaHostUnregister(x.data_ptr())
+                if int(torch.cuda.cudart().cudaHostUnregister(x.data_ptr())) != 0:
+                    self.lib.gf3_clear_runtime_error()
 
     def _receive_host(self, x, pinned_in, registered, chunk_samples, list_cap, t_start):
         import time
@@ -505,12 +519,12 @@ class Engine:
         # Device buffers, workspace, pinned staging, the copy stream and its events are kept between calls (per host
         # thread: two threads may ingest through one Engine at once) and reused while the sizes fit: a receiver that is
         # fed one recording after another does not allocate per call.
-        key = (nbuf, cap_list, cap_peaks, bool(pinned_in), cfg.in_dtype, min(2, nchunks))
+        key = (nbuf, cap_list, cap_peaks, bool(pinned_in), cfg.in_dtype, min(3, nchunks))
         res = getattr(self._tls, "ingest", None)
         if res is None or res["key"] != key:
             res = dict(key=key, copier=torch.cuda.Stream(dev),
                        bufs=[self._new((nbuf,), cfg.in_dtype) for _ in range(min(2, nchunks))],
-                       stage=None if pinned_in else [torch.empty((min(H, n),), dtype=cfg.in_dtype).pin_memory() for _ in range(min(2, nchunks))],
+                       stage=None if pinned_in else [torch.empty((min(H, n),), dtype=cfg.in_dtype).pin_memory() for _ in range(min(3, nchunks))],
                        idx_all=self._new((cap_list,), torch.int64), val_all=self._new((cap_list, 3), torch.float64),
                        work=self._new((int(self.lib.gf3_sync_chunk_workspace_bytes(self._h, nbuf)),), torch.uint8),
                        peaks_dev=self._new((cap_peaks,), torch.int64),
@@ -540,13 +554,13 @@ class Engine:
         staged = {}                                               # piece -> future of its host-side staging copy
 
         def stage_piece(c):
-            """pageable source, registration refused: piece c's new samples -> pinned staging buffer c % 2 (a host copy by
-            four threads), once the DMA that last read that buffer has finished.  Runs on the stager thread, TWO pieces
-            ahead of the kernels: under piece c - 2's kernels and piece c - 1's DMA."""
-            b = c % 2
+            """pageable source, registration refused: piece c's new samples -> pinned staging buffer c % 3 (a host copy by
+            four threads).  Runs on the stager thread, TWO pieces ahead of the kernels -- under piece c - 2's kernels and
+            piece c - 1's DMA.  The buffer was last read by the DMA of piece c - 3, which the calling thread has seen
+            finish (it synchronised on piece c - 3's kernels, which waited for that DMA) before it submits this: a plain
+            host memcpy, no HIP call on this thread."""
             lo_s, hi_s = c * H, min(n, (c + 1) * H)
-            src, dst, m = x[lo_s:hi_s], stage[b], hi_s - lo_s
-            ev_copied[b].synchronize()                            # the copy that last read this staging buffer is done
+            src, dst, m = x[lo_s:hi_s], stage[c % 3], hi_s - lo_s
             if m >= (1 << 22):                                     # four host threads: 24 GB/s on the GPU box against 4 GB/s for one
                 q = -(-m // 4)
                 list(res["pool"].map(lambda k: dst[k * q: min(m, (k + 1) * q)].copy_(src[k * q: min(m, (k + 1) * q)]), range(4)))
@@ -560,13 +574,11 @@ class Engine:
             src = x[lo_s:hi_s]
             if stage is not None:
                 staged.pop(c).result()                            # (staged while the previous piece's kernels ran)
-                src = stage[b][: hi_s - lo_s]
+                src = stage[c % 3][: hi_s - lo_s]
             with torch.cuda.stream(copier):
                 bufs[b][carry: carry + (hi_s - lo_s)].copy_(src, non_blocking=True)
                 ev_copied[b].record(copier)
             info["h2d_bytes"] += (hi_s - lo_s) * x.element_size()
-            if stage is not None and c + 2 < nchunks:             # the staging buffer is free again once this DMA is done
-                staged[c + 2] = res["stager"].submit(stage_piece, c + 2)
 
         def sync_piece(buf, n_buf, lag_lo, lag_hi, base, idx_t, val_t, cap):
             """-> (entries listed, or -(entries wanted) - 1 when they do not fit; the piece's own maximum)"""
@@ -586,8 +598,14 @@ class Engine:
 
         info["setup_seconds"] = time.perf_counter() - t_start    # (pinned staging, device buffers, workspace: cached by torch after the first call)
         if stage is not None:
+            for fut in res.pop("pending", []):                     # (a previous call that ended in an exception may have left copies running)
+                try:
+                    fut.result()
+                except Exception:
+                    pass
             for c0 in range(min(2, nchunks)):
                 staged[c0] = res["stager"].submit(stage_piece, c0)
+            res["pending"] = staged.values()
         issue_copy(0)
         for c in range(nchunks):
             b = c % 2
@@ -601,6 +619,10 @@ class Engine:
                 ev_order.record(main)                              # the other buffer is free once this point is reached
                 copier.wait_event(ev_order)
                 issue_copy(c + 1)                                  # its DMA runs under this piece's kernels
+            if stage is not None and c + 2 < nchunks:
+                # ... and piece c + 2 is staged meanwhile, into the buffer piece c - 1 was copied from: that DMA is
+                # known to be finished (this thread synchronised on piece c - 1's kernels, which had waited for it)
+                staged[c + 2] = res["stager"].submit(stage_piece, c + 2)
             buf = bufs[b][carry - ce: carry + (hi_s - lo_s)]
             room = cap_list - n_listed                             # (a full list: the piece can only report that it overflows, or keep nothing)
             info["full_list_pieces"] += int(room == 0)

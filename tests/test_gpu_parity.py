@@ -1398,8 +1398,8 @@ def test_unpack_decode_kernel_matches_numpy(C, mu, D):
 def test_receive_host_list_exactly_full_and_refused_registration(tmp_path):
     """ (i) a kept-lag list that is EXACTLY full when a piece begins: the piece is offered no room (cap 0, no
     buffers) and is either empty or overflows into the second look -- for every capacity from 1 to the number of lags
-    the stream keeps, the detections and bits are the oracle's; (ii) a source the runtime refuses to pin in place (a
-    read-only file mapping): the refusal is cleared, the staging path (host copies two pieces ahead, on a background
+    the stream keeps, the detections and bits are the oracle's; (ii) a read-only file mapping is staged, never pinned in
+    place; a registration the runtime refuses is cleared, the staging path (host copies two pieces ahead, on a background
     thread) gives the same result, and the next unrelated launch sees no stale error."""
     g = load("g1_n1024_qpsk")
     p = params_of(g)
@@ -1418,16 +1418,29 @@ def test_receive_host_list_exactly_full_and_refused_registration(tmp_path):
         assert torch.equal(out["bits"], base["bits"]), cap
     assert full >= 1                                                    # some capacity left a piece no room at all
     assert np.array_equal(eng.unpack_bits(base["bits"]).cpu().numpy(), ref["bits"])
-    # (ii)
+    # (ii) a read-only file mapping is never pinned in place (the staging path takes it) ...
     path = tmp_path / "stream.f64"
     r.tofile(path)
     ro = np.memmap(path, dtype=np.float64, mode="r")
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")                                 # (torch warns about wrapping a non-writable array)
-        out = eng.receive_host(ro, chunk_samples=1, pin_in_place=True)
+    out = eng.receive_host(ro, chunk_samples=1, pin_in_place=True)
+    assert not out["info"]["pinned_in_place"] and not out["info"]["pinned_input"], out["info"]
     assert np.array_equal(out["peaks"].cpu().numpy(), want_peaks) and torch.equal(out["bits"], base["bits"])
-    assert eng.lib.gf3_clear_runtime_error() == 0                       # nothing left behind, whichever way the registration went
+    del ro
+    # ... and a registration the runtime REFUSES (here: made to fail) is cleared and falls back to staging as well
+    class _Refusing:
+        def __init__(self, rt): self.rt = rt
+        def cudaHostRegister(self, ptr, size, flags):
+            return self.rt.cudaHostRegister(0, 4096, 0)                 # a NULL range: a real refusal, with its real sticky error
+        def __getattr__(self, k): return getattr(self.rt, k)
+    real = torch.cuda.cudart
+    torch.cuda.cudart = lambda: _Refusing(real())
+    try:
+        out = eng.receive_host(r, chunk_samples=1, pin_in_place=True)
+    finally:
+        torch.cuda.cudart = real
+    assert not out["info"]["pinned_in_place"], out["info"]
+    assert np.array_equal(out["peaks"].cpu().numpy(), want_peaks) and torch.equal(out["bits"], base["bits"])
+    assert eng.lib.gf3_clear_runtime_error() == 0                       # nothing left behind for the next launch check
     assert torch.equal(eng.sync_stream(torch.from_numpy(r).cuda()), out["peaks"])
     staged = eng.receive_host(r, chunk_samples=1, pin_in_place=False)   # the fallback itself, forced: many pieces, pipeline two ahead
     assert staged["info"]["chunks"] >= 4 and not staged["info"]["pinned_input"]
