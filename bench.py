@@ -736,6 +736,9 @@ def main():
         os.environ["NCCL_ALGO"] = args.gather_algo         # (inherited by the ranks launch_ranks starts)
     if args.gather_proto:
         os.environ["NCCL_PROTO"] = args.gather_proto
+    # RCCL's own stream at high priority, so that the per-chunk all-gathers never share a hardware queue with the compute
+    # streams they are meant to run under (recorded with the collective's other settings)
+    os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))        # the children run the rest of main() with WORLD_SIZE set
     if args.frames <= 0:
@@ -777,7 +780,9 @@ def main():
             self.og = gd.OverlappedGather(self.gathered, F, self.chunks) if (multi and gather) else None
             self.starts_all = torch.empty((F,), dtype=torch.int64, device=dev)
             self.starts_c = torch.empty((self.chunks, self.Fc), dtype=torch.int64, device=dev)   # per-chunk sync results (chunk-relative)
-            self.s_sync = torch.cuda.Stream() if multi else None      # chunked path: sync kernels run ahead on their own stream
+            # (a HIGH-PRIORITY stream: streams of one priority level can share a hardware queue, which would serialise the sync
+            #  launches behind the demod launches they are meant to run ahead of -- DESIGN 3.2 has the measurement that showed it)
+            self.s_sync = torch.cuda.Stream(priority=-1) if multi else None   # chunked path: sync kernels run ahead on their own stream
             self.s_dem2 = torch.cuda.Stream() if multi else None      # ... and odd chunks' demod kernels on a second one
             self.ev_sync = [torch.cuda.Event() for _ in range(self.chunks)]
             self.ev_step = torch.cuda.Event()
@@ -1027,7 +1032,7 @@ def main():
             "sustained_2s": sustained,
             "collective": ({"backend": torch.distributed.get_backend(), "library_version": rccl_version(),
                             "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"),
-                            "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))},
+                            "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "TORCH_NCCL_"))},
                             "note": "algorithm / protocol are RCCL's own choice unless NCCL_ALGO / NCCL_PROTO are set "
                                     "(--gather-algo / --gather-proto)"} if multi else None),
             "library": {"version": ver, "source_sha16": src},
