@@ -6,6 +6,8 @@
 //   gf3rx_demod_split.hip, gf3rx_dsplit_{qpsk,scan,full}.hip   the two-phase demodulation of long packets
 //   gf3rx_corr.hip           corr_kernel, spec_kernel, ols_kernel
 //   gf3rx_screen.hip         scr_ring_kernel, scr_ols_kernel, scr_refine_kernel (gf3rx_screen.h)
+//   gf3rx_fscreen.hip        corr_screen_kernel: the opt-in fp32 screen of the frames-mode sync (gf3rx_fscreen.h)
+//   gf3rx_stamp.cpp          the build stamp (source hash), recompiled on every change
 //   gf3rx_sync.hip           pk_*, ck_*, scr list kernels + gf3_sync_stream*, gf3_sync_chunk, gf3_sync_decide
 //   gf3rx_abi.hip            context, plans, the remaining entry points, demappers, zero forcing, Schmidl-Cox
 #pragma once
