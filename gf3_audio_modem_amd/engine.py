@@ -243,10 +243,10 @@ class Engine:
         if "slope" in want: o["slope"] = self._new((F,), torch.float64)
         if "Hest" in want: o["Hest"] = self._new((F, cfg.D, cfg.K), torch.complex128)
         if "status" in want: o["status"] = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        # the two-phase form needs a workspace (pilot sums, and Hs / He / slope when they are not asked for): only ever
-        # chosen for a few packets, so it is only allocated for a few
+        # the two-phase form needs a workspace (pilot sums, and Hs / He / slope when they are not asked for): allocated exactly
+        # when the library would choose that form (at most 2 x CUs packets)
         work = None
-        if split or (split is None and F * 4 <= self.n_cu):
+        if F and (split or (split is None and self.lib.gf3_demod_split_plan(self._h, F, 0, None, None))):
             work = self._new((int(self.lib.gf3_demod_workspace_bytes(self._h, F)),), torch.uint8)
         self._check(self.lib.gf3_demod_frames_ex(
             self._h, _ptr(x), x.numel(), _ptr(off), F, _ptr(bits), _ptr(o.get("eq")), _ptr(o.get("Hs")),
@@ -259,8 +259,6 @@ class Engine:
         its data stage, chunks: workgroups per packet)."""
         dc, nch = C.c_int32(0), C.c_int32(0)
         two = self.lib.gf3_demod_split_plan(self._h, int(F), 0 if split is None else (2 if split else 1), C.byref(dc), C.byref(nch))
-        if split is None and F * 4 > self.n_cu:
-            two = 0                                               # (no workspace is allocated for batches)
         return dict(split=bool(two), Dc=int(dc.value), chunks=int(nch.value))
 
     def equalise(self, data, start, end, want=("Hest",)):

@@ -148,7 +148,8 @@ int gf3_demod_frames(gf3_ctx *ctx, const void *d_in, int64_t n_in,
  * Outputs are those of gf3_demod_frames: Hs / He / slope bit for bit, equalised symbols to ~1e-13 (the phasor of a
  * chunk's first symbol is computed directly instead of by recurrence), bits identical.
  *   d_work   gf3_demod_workspace_bytes(ctx, F) bytes of device memory, or NULL (then always the one-launch kernel)
- *   mode     0: the library chooses by F and D (two-phase when F <= CUs / 4 and a packet cuts into >= 4 chunks)
+ *   mode     0: the library chooses by F and D (two-phase when F <= 2 x CUs and a packet cuts into >= 2 chunks of the
+ *               length that fills the chip once -- the measured crossover, tools/ab/time_split.py)
  *            1: always the one-launch kernel      2: two-phase whenever d_work is given
  */
 int64_t gf3_demod_workspace_bytes(const gf3_ctx *ctx, int64_t F);
