@@ -457,6 +457,50 @@ def test_config3_full_size_stream():
     assert 0.0 < res["ber"] < 0.05
 
 
+def test_stream_past_2_31_samples():
+    """Maximum sizes: ONE stream of 2.15 G samples (27 500 config-3 packets through the measured channel), so that lag and
+    sample indices pass 2^31 in every stage of the stream path.  Every chirp is found where it was put (screened and
+    all-fp64 evaluation), the packets that lie wholly beyond sample 2^31 decode to the oracle's bits, and the same stream
+    taken from host memory in 17 pieces gives the same peaks and the same bits."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("config3_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "config3.py"))
+    tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
+    eng, cfg, channel = tool.make_engine()
+    F = 27500
+    r, payload = tool.make_stream(eng, channel, F, seed=5)
+    assert r.numel() > 2 ** 31 + 2 * cfg.frame_len
+    res, starts, out = tool.measure(eng, cfg, r, payload, reps=1, warm=0, worst=4, fp64_reps=1)   # (asserts: F packets, fp64 peaks == screened)
+    assert res["sync_offsets_as_expected_plus1"] and 0.0 < res["ber"] < 0.05, res
+    st = starts.cpu().numpy()
+    beyond = np.flatnonzero(st >= 2 ** 31)
+    assert len(beyond) >= 2 and st[-1] + cfg.M * cfg.S > 2 ** 31
+    pts, bt = orc.square_qam_table(4)
+    known = load("g3_n4096_16qam_gr5")["known_bits"].astype(np.uint8)
+    p = orc.RxParams(N=4096, CP=512, P=2, D=8, lo=1, hi=2047, const_points=pts, const_bits=bt.astype(np.int64), known_bits=known)
+    pick = np.unique(np.concatenate([beyond, [beyond[0] - 1, 0], np.asarray(res["worst_packets"])]))     # (beyond[0] - 1 straddles 2^31)
+    L = cfg.M * cfg.S
+    segs = np.stack([r[int(st[f]): int(st[f]) + L].cpu().numpy().astype(np.float64) for f in pick])
+    ref = orc.demod_frames(segs.reshape(-1), np.arange(len(pick)) * L, p)["bits"].reshape(len(pick), -1)
+    got = np.unpackbits(out[torch.as_tensor(pick, device=out.device)].cpu().numpy(), axis=1)[:, : cfg.bits_per_frame]
+    assert np.array_equal(ref, got)
+    # ---- the stand-alone transform and the frames-mode sync at offsets past 2^31
+    offs = np.array([2 ** 31 + 12345, r.numel() - cfg.N], dtype=np.int64)
+    X = eng.rfft_batch(r, offs).cpu().numpy()
+    for i, o in enumerate(offs):
+        want = np.fft.rfft(r[int(o): int(o) + cfg.N].cpu().numpy().astype(np.float64))
+        assert np.abs(X[i] - want).max() <= 1e-12 * np.abs(want).max()
+    fs = eng.sync_frames(r, F, cfg.frame_len, 64 - 8, 64 + 248)      # the stream read as F rows of one packet each, a window around every chirp
+    assert np.array_equal(fs.cpu().numpy(), st)
+    # ---- the host-memory entry over the same samples
+    host = torch.empty(r.numel(), dtype=r.dtype).pin_memory()
+    host.copy_(r); torch.cuda.synchronize()
+    peaks = eng.sync_stream(r)
+    del r
+    hr = eng.receive_host(host, chunk_samples=1 << 27)
+    assert hr["info"]["chunks"] >= 16 and hr["info"]["h2d_bytes"] >= host.numel() * 4, hr["info"]
+    assert torch.equal(hr["peaks"], peaks) and torch.equal(hr["bits"], out)
+
+
 def test_degenerate_packets_follow_the_reference_tie_rule():
     """All-zero, NaN and Inf packets: H = 0/NaN, X/H = NaN, and the reference's argmin returns the first
     constellation point (bits 00) for every carrier.  The sign-rule fast path must fall back to the
@@ -1239,6 +1283,9 @@ def test_split_path_on_the_real_recording(storage):
     eng = engine_for(p, in_dtype=torch.uint8 if storage == "u8" else torch.float64)
     plan = eng.demod_plan(3)
     assert plan["split"] and plan["chunks"] >= 4 and (plan["Dc"] * p.C * p.mu) % 32 == 0, plan
+    # the rule of gf3rx.h (mode 0): two-phase while a packet cuts into two chunks or more and F <= 2 x CUs
+    assert eng.demod_plan(2 * eng.n_cu)["split"] == (eng.demod_plan(2 * eng.n_cu)["chunks"] >= 2)
+    assert not eng.demod_plan(2 * eng.n_cu + 1)["split"] and not eng.demod_plan(65536)["split"]
     x = torch.from_numpy(r).cuda()
     starts = torch.from_numpy(np.asarray(g["peaks"][:-1]) + 2).cuda()
     one, two = _same_as_one_launch(eng, x, starts, ("eq", "Hest", "Hs", "He", "slope"))
