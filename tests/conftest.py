@@ -27,3 +27,30 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_sessionstart(session):
+    """GPU runs only: a C-level SIGABRT handler (tests/abort_trace.c) that records the C backtrace of the aborting thread
+    and the tail of the captured stderr -- a process killed by abort() inside the runtime leaves pytest nothing to print.
+    Test infrastructure; any failure to set it up is ignored."""
+    if not _has_gpu():
+        return
+    try:
+        import resource
+        resource.setrlimit(resource.RLIMIT_CORE, (0, 0))   # (a core file of a process holding tens of GB takes minutes to write)
+    except Exception:
+        pass
+    try:
+        import ctypes, subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        so, src = os.path.join(here, "_abort_trace.so"), os.path.join(here, "abort_trace.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", so, src], check=True, capture_output=True, timeout=120)
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        lib = ctypes.CDLL(so)
+        lib.gf3_install_abort_trace.argtypes = [ctypes.c_char_p]
+        lib.gf3_install_abort_trace(os.path.join(out_dir, "abort_trace.txt").encode())
+        session.config._gf3_abort_trace = lib            # (keeps the library loaded)
+    except Exception:
+        pass
