@@ -430,7 +430,7 @@ class Engine:
         return llr
 
     # ------------------------------------------------------------------ host ingest (streams from host memory / longer than HBM)
-    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None, pin_in_place=True):
+    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None, pin_in_place=True, pin_min_bytes=64 << 20):
         """chirp sync + demodulation (the arithmetic of receiver.receive, OFDM.py:581-603) of a stream that lives in
         HOST memory, piece by piece: pinned, double-buffered H2D copies on a copy stream run under the kernels of the
         previous piece, and the result is that of the one-shot path -- the reference's rule with the GLOBAL maximum
@@ -444,8 +444,10 @@ class Engine:
         kill an earlier candidate, or un-suppressed one) are packets looked at again -- their samples re-read from the
         host array.  Pieces overlap by Lc + one packet, so no chirp and no packet is cut.
 
-        samples: 1-D numpy array or CPU torch tensor (a pinned tensor is copied from directly; pageable memory is pinned
-        in place for the duration of the call, or, if that is refused, staged through THREE pinned buffers by a host copy
+        samples: 1-D numpy array or CPU torch tensor (a pinned tensor is copied from directly; pageable memory of at
+        least pin_min_bytes -- 64 MiB: an allocation of that size is a mapping of its own, whose pages hold nothing else --
+        is pinned in place for the duration of the call; smaller arrays, read-only arrays, file mappings and arrays whose
+        registration is refused are staged through THREE pinned buffers by a host copy
         per piece that a background thread makes two pieces ahead of the kernels: under piece c's kernels and piece c+1's
         DMA, piece c+2 is being staged -- into the buffer piece c-1 was copied from, which is idle by then, so the thread
         makes no HIP call at all).  chunk_samples: new samples per piece (raised to
@@ -480,6 +482,10 @@ class Engine:
         n = x.numel()
         if n < 3:
             raise ValueError("stream too short")
+        # Nor is a small array: below glibc's largest mmap threshold (32 MiB) an allocation can be a piece of the heap, and
+        # registering it would hand pages that also hold unrelated objects -- the runtime's own among them -- to the driver.
+        if n * x.element_size() < int(pin_min_bytes):
+            pin_in_place = False
         # Pageable input is PINNED IN PLACE for the duration of the call (hipHostRegister: 3 ms for 1.3 GB on the GPU box, after
         # which the copies run at the pinned rate, 57 GB/s; staging every piece through a pinned buffer by a host copy runs at
         # 4 GB/s on one thread).  Staging remains the fallback when the registration is refused.
@@ -495,6 +501,9 @@ class Engine:
                 self.lib.gf3_clear_runtime_error()
         try:
             return self._receive_host(x, x.is_pinned() or registered, registered, chunk_samples, list_cap, t_start)
+        except BaseException:
+            torch.cuda.synchronize(self.device)                    # nothing of the call is in flight when its buffers are let go
+            raise
         finally:
             if registered:
                 torch.cuda.synchronize(self.device)

@@ -1151,11 +1151,12 @@ def _config1_case():
     return g, p, F, r
 
 
-@pytest.mark.parametrize("storage", ["f64_pageable", "f64_staged", "f32_pinned"])
+@pytest.mark.parametrize("storage", ["f64_pageable", "f32_pinned"])
 def test_receive_host_chunked_equals_one_shot_and_reference(storage):
     """BASELINE config 1 (64 frames, the reference's own bits in the g1b fixture) from HOST memory in 33 pieces of
-    two packets each -- pageable (pinned in place), pageable and staged, pinned -- : peaks and bits of the one-shot device
-    path and of the reference."""
+    two packets each -- pageable (10 MB: staged through pinned buffers two pieces ahead; only arrays of 64 MiB and more
+    are pinned in place, test_receive_host_pins_a_large_pageable_array_in_place) and pinned -- : peaks and bits of the
+    one-shot device path and of the reference."""
     g, p, F, r = _config1_case()
     dt = torch.float64 if storage.startswith("f64") else torch.float32
     eng = engine_for(p, in_dtype=dt)
@@ -1164,10 +1165,9 @@ def test_receive_host_chunked_equals_one_shot_and_reference(storage):
         ref_bits = orc.receive(r.astype(np.float32).astype(np.float64), p)["bits"]
     else:
         host, ref_bits = r, unpack(g)
-    out = eng.receive_host(host, chunk_samples=1, pin_in_place=storage != "f64_staged")     # (raised to two packets per piece)
+    out = eng.receive_host(host, chunk_samples=1)                       # (raised to two packets per piece)
     info = out["info"]
-    # pageable memory is pinned in place for the call; "staged" forces the fallback (a host copy per piece into pinned buffers)
-    assert info["chunks"] >= 4 and info["pinned_input"] == (storage != "f64_staged") and info["pinned_in_place"] == (storage == "f64_pageable"), info
+    assert info["chunks"] >= 4 and info["pinned_input"] == (storage == "f32_pinned") and not info["pinned_in_place"], info
     x = torch.as_tensor(host).cuda()
     one = eng.sync_stream(x)
     assert torch.equal(out["peaks"], one) and out["peaks"].numel() == F + 1
@@ -1469,7 +1469,7 @@ def test_receive_host_list_exactly_full_and_refused_registration(tmp_path):
     path = tmp_path / "stream.f64"
     r.tofile(path)
     ro = np.memmap(path, dtype=np.float64, mode="r")
-    out = eng.receive_host(ro, chunk_samples=1, pin_in_place=True)
+    out = eng.receive_host(ro, chunk_samples=1, pin_in_place=True, pin_min_bytes=0)
     assert not out["info"]["pinned_in_place"] and not out["info"]["pinned_input"], out["info"]
     assert np.array_equal(out["peaks"].cpu().numpy(), want_peaks) and torch.equal(out["bits"], base["bits"])
     del ro
@@ -1482,7 +1482,7 @@ def test_receive_host_list_exactly_full_and_refused_registration(tmp_path):
     real = torch.cuda.cudart
     torch.cuda.cudart = lambda: _Refusing(real())
     try:
-        out = eng.receive_host(r, chunk_samples=1, pin_in_place=True)
+        out = eng.receive_host(r, chunk_samples=1, pin_in_place=True, pin_min_bytes=0)
     finally:
         torch.cuda.cudart = real
     assert not out["info"]["pinned_in_place"], out["info"]
@@ -1492,6 +1492,29 @@ def test_receive_host_list_exactly_full_and_refused_registration(tmp_path):
     staged = eng.receive_host(r, chunk_samples=1, pin_in_place=False)   # the fallback itself, forced: many pieces, pipeline two ahead
     assert staged["info"]["chunks"] >= 4 and not staged["info"]["pinned_input"]
     assert torch.equal(staged["peaks"], out["peaks"]) and torch.equal(staged["bits"], base["bits"])
+
+
+def test_receive_host_pins_a_large_pageable_array_in_place():
+    """A pageable array of 64 MiB or more (a mapping of its own) is registered for the duration of the call and copied
+    from at the pinned rate: 256 config-3 packets (80 MB of f32) in 20 pieces -- the peaks and bits of the one-shot path,
+    every sample over PCIe once, the registration gone afterwards."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("config3_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "config3.py"))
+    tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
+    eng, cfg, channel = tool.make_engine()
+    r, payload = tool.make_stream(eng, channel, 256, seed=11)
+    host = r.cpu().numpy()
+    assert host.nbytes >= 64 << 20 and not torch.from_numpy(host).is_pinned()
+    out = eng.receive_host(host, chunk_samples=1 << 20)
+    info = out["info"]
+    assert info["pinned_in_place"] and info["pinned_input"] and info["chunks"] >= 16 and info["h2d_bytes"] == host.nbytes, info
+    assert not torch.from_numpy(host).is_pinned()                      # unregistered again
+    one = eng.sync_stream(r)
+    assert torch.equal(out["peaks"], one) and one.numel() == 257
+    assert torch.equal(out["bits"], eng.demod_frames(r, (one + 2)[:-1])["bits"])
+    small = eng.receive_host(host[: 64 + 40 * cfg.frame_len + cfg.chirp_length + 200].copy(), chunk_samples=1 << 20)   # 12.6 MB: staged
+    assert not small["info"]["pinned_in_place"] and not small["info"]["pinned_input"]
+    assert torch.equal(small["peaks"], one[:41]) and torch.equal(small["bits"], out["bits"][:40])
 
 
 # ---------------------------------------------------------------------------------------------------------------
