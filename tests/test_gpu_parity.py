@@ -1503,7 +1503,7 @@ def test_receive_host_pins_a_large_pageable_array_in_place():
     tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
     eng, cfg, channel = tool.make_engine()
     r, payload = tool.make_stream(eng, channel, 256, seed=11)
-    host = r.cpu().numpy()
+    host = r.cpu().numpy().copy()                                      # (an array that owns its memory, as wavfile.read returns)
     assert host.nbytes >= 64 << 20 and not torch.from_numpy(host).is_pinned()
     out = eng.receive_host(host, chunk_samples=1 << 20)
     info = out["info"]
