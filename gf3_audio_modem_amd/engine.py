@@ -8,6 +8,7 @@ library, constructing an Engine raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from dataclasses import dataclass, field
 
@@ -430,7 +431,7 @@ class Engine:
         return llr
 
     # ------------------------------------------------------------------ host ingest (streams from host memory / longer than HBM)
-    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None, pin_in_place=True, pin_min_bytes=64 << 20):
+    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None, pin_in_place=True, pin_min_bytes=None):
         """chirp sync + demodulation (the arithmetic of receiver.receive, OFDM.py:581-603) of a stream that lives in
         HOST memory, piece by piece: pinned, double-buffered H2D copies on a copy stream run under the kernels of the
         previous piece, and the result is that of the one-shot path -- the reference's rule with the GLOBAL maximum
@@ -484,6 +485,8 @@ class Engine:
             raise ValueError("stream too short")
         # Nor is a small array: below glibc's largest mmap threshold (32 MiB) an allocation can be a piece of the heap, and
         # registering it would hand pages that also hold unrelated objects -- the runtime's own among them -- to the driver.
+        if pin_min_bytes is None:
+            pin_min_bytes = int(os.environ.get("GF3_PIN_MIN_BYTES", 64 << 20))
         if n * x.element_size() < int(pin_min_bytes):
             pin_in_place = False
         # Pageable input is PINNED IN PLACE for the duration of the call (hipHostRegister: 3 ms for 1.3 GB on the GPU box, after
