@@ -431,7 +431,7 @@ class Engine:
         return llr
 
     # ------------------------------------------------------------------ host ingest (streams from host memory / longer than HBM)
-    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None, pin_in_place=True, pin_min_bytes=None):
+    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None, pin_in_place=False, pin_min_bytes=None):
         """chirp sync + demodulation (the arithmetic of receiver.receive, OFDM.py:581-603) of a stream that lives in
         HOST memory, piece by piece: pinned, double-buffered H2D copies on a copy stream run under the kernels of the
         previous piece, and the result is that of the one-shot path -- the reference's rule with the GLOBAL maximum
@@ -445,10 +445,13 @@ class Engine:
         kill an earlier candidate, or un-suppressed one) are packets looked at again -- their samples re-read from the
         host array.  Pieces overlap by Lc + one packet, so no chirp and no packet is cut.
 
-        samples: 1-D numpy array or CPU torch tensor (a pinned tensor is copied from directly; pageable memory of at
-        least pin_min_bytes -- 64 MiB: an allocation of that size is a mapping of its own, whose pages hold nothing else --
-        is pinned in place for the duration of the call; smaller arrays, read-only arrays, file mappings and arrays whose
-        registration is refused are staged through THREE pinned buffers by a host copy
+        samples: 1-D numpy array or CPU torch tensor.  A pinned tensor is copied from directly.  Pageable memory is staged
+        through THREE pinned buffers (below); with pin_in_place=True an array of at least pin_min_bytes -- 64 MiB: an
+        allocation of that size is a mapping of its own, whose pages hold nothing else -- is instead registered with the
+        driver for the duration of the call and copied from at the pinned rate (twice the staged one).  That is an opt-in:
+        registering and releasing ranges of ordinary process memory over and over was followed, in this package's own test
+        runs, by GPU memory faults in unrelated kernels later in the process; read-only arrays and file
+        mappings are never registered.  Staging: a host copy
         per piece that a background thread makes two pieces ahead of the kernels: under piece c's kernels and piece c+1's
         DMA, piece c+2 is being staged -- into the buffer piece c-1 was copied from, which is idle by then, so the thread
         makes no HIP call at all).  chunk_samples: new samples per piece (raised to

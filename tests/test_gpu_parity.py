@@ -1154,8 +1154,8 @@ def _config1_case():
 @pytest.mark.parametrize("storage", ["f64_pageable", "f32_pinned"])
 def test_receive_host_chunked_equals_one_shot_and_reference(storage):
     """BASELINE config 1 (64 frames, the reference's own bits in the g1b fixture) from HOST memory in 33 pieces of
-    two packets each -- pageable (10 MB: staged through pinned buffers two pieces ahead; only arrays of 64 MiB and more
-    are pinned in place, test_receive_host_pins_a_large_pageable_array_in_place) and pinned -- : peaks and bits of the
+    two packets each -- pageable (staged through pinned buffers two pieces ahead; pinning in place is an opt-in for large
+    arrays, test_receive_host_pins_a_large_pageable_array_in_place) and pinned -- : peaks and bits of the
     one-shot device path and of the reference."""
     g, p, F, r = _config1_case()
     dt = torch.float64 if storage.startswith("f64") else torch.float32
@@ -1495,8 +1495,8 @@ def test_receive_host_list_exactly_full_and_refused_registration(tmp_path):
 
 
 def test_receive_host_pins_a_large_pageable_array_in_place():
-    """A pageable array of 64 MiB or more (a mapping of its own) is registered for the duration of the call and copied
-    from at the pinned rate: 256 config-3 packets (80 MB of f32) in 20 pieces -- the peaks and bits of the one-shot path,
+    """Opt-in (pin_in_place=True): a pageable array of 64 MiB or more (a mapping of its own) is registered for the duration of
+    the call and copied from at the pinned rate: 256 config-3 packets (80 MB of f32) in 20 pieces -- the peaks and bits of the one-shot path,
     every sample over PCIe once, the registration gone afterwards."""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("config3_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "config3.py"))
@@ -1505,14 +1505,14 @@ def test_receive_host_pins_a_large_pageable_array_in_place():
     r, payload = tool.make_stream(eng, channel, 256, seed=11)
     host = r.cpu().numpy().copy()                                      # (an array that owns its memory, as wavfile.read returns)
     assert host.nbytes >= 64 << 20 and not torch.from_numpy(host).is_pinned()
-    out = eng.receive_host(host, chunk_samples=1 << 20)
+    out = eng.receive_host(host, chunk_samples=1 << 20, pin_in_place=True)
     info = out["info"]
     assert info["pinned_in_place"] and info["pinned_input"] and info["chunks"] >= 16 and info["h2d_bytes"] == host.nbytes, info
     assert not torch.from_numpy(host).is_pinned()                      # unregistered again
     one = eng.sync_stream(r)
     assert torch.equal(out["peaks"], one) and one.numel() == 257
     assert torch.equal(out["bits"], eng.demod_frames(r, (one + 2)[:-1])["bits"])
-    small = eng.receive_host(host[: 64 + 40 * cfg.frame_len + cfg.chirp_length + 200].copy(), chunk_samples=1 << 20)   # 12.6 MB: staged
+    small = eng.receive_host(host[: 64 + 40 * cfg.frame_len + cfg.chirp_length + 200].copy(), chunk_samples=1 << 20, pin_in_place=True)   # 12.6 MB: staged all the same
     assert not small["info"]["pinned_in_place"] and not small["info"]["pinned_input"]
     assert torch.equal(small["peaks"], one[:41]) and torch.equal(small["bits"], out["bits"][:40])
 

@@ -31,7 +31,7 @@ if FRAMES <= 4096:                                          # pageable input: pi
     pageable = host.numpy().copy()
     ts = []
     for _ in range(3):
-        t = time.perf_counter(); res2 = eng.receive_host(pageable, chunk_samples=1 << 25); ts.append(time.perf_counter() - t)
+        t = time.perf_counter(); res2 = eng.receive_host(pageable, chunk_samples=1 << 25, pin_in_place=True); ts.append(time.perf_counter() - t)
     t = float(np.median(ts[1:]))
     print("receive_host from PAGEABLE memory (pinned in place: %s): %.2f ms = %.1f GB/s, %.2f G samples/s; peaks equal: %s" % (
         res2["info"]["pinned_in_place"], t * 1e3, n * 4 / t / 1e9, n / t / 1e9, bool(torch.equal(res2["peaks"], res["peaks"]))), flush=True)
