@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 static int g_fd = -1;
+static int g_fd2 = -1;          /* the terminal's stderr as it was before pytest's capture, if known */
 static struct sigaction g_prev;
 
 static void put(int fd, const char *s) { if (fd >= 0) { ssize_t r = write(fd, s, strlen(s)); (void)r; } }
@@ -38,6 +39,21 @@ static void on_abort(int sig, siginfo_t *si, void *uc) {
         }
     }
     if (g_fd >= 0) fsync(g_fd);
+    if (g_fd2 >= 0) {                          /* the same two things where the run's log will show them */
+        put(g_fd2, "\n==== SIGABRT: C backtrace of the aborting thread ====\n");
+        backtrace_symbols_fd(frames, n, g_fd2);
+        if (fstat(2, &st) == 0 && S_ISREG(st.st_mode)) {
+            static char buf2[4096];
+            const off_t end = lseek(2, 0, SEEK_CUR);
+            if (end > 0) {
+                const off_t from = end > (off_t)sizeof buf2 ? end - (off_t)sizeof buf2 : 0;
+                const ssize_t got = pread(2, buf2, (size_t)(end - from), from);
+                put(g_fd2, "==== tail of the captured stderr ====\n");
+                if (got > 0) { ssize_t r = write(g_fd2, buf2, (size_t)got); (void)r; }
+                put(g_fd2, "\n==== end ====\n");
+            }
+        }
+    }
     /* hand on: faulthandler's handler (Python frames), or the default action */
     if ((g_prev.sa_flags & SA_SIGINFO) && g_prev.sa_sigaction) g_prev.sa_sigaction(sig, si, uc);
     else if (!(g_prev.sa_flags & SA_SIGINFO) && g_prev.sa_handler != SIG_DFL && g_prev.sa_handler != SIG_IGN) g_prev.sa_handler(sig);
@@ -45,7 +61,8 @@ static void on_abort(int sig, siginfo_t *si, void *uc) {
     raise(SIGABRT);
 }
 
-int gf3_install_abort_trace(const char *path) {
+int gf3_install_abort_trace(const char *path, int terminal_fd) {
+    g_fd2 = terminal_fd;
     void *warm[4];
     (void)backtrace(warm, 4);                  /* loads the unwinder now, not inside the handler */
     g_fd = open(path, O_WRONLY | O_CREAT | O_APPEND, 0644);

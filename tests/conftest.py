@@ -49,8 +49,14 @@ def pytest_sessionstart(session):
         out_dir = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out_dir, exist_ok=True)
         lib = ctypes.CDLL(so)
-        lib.gf3_install_abort_trace.argtypes = [ctypes.c_char_p]
-        lib.gf3_install_abort_trace(os.path.join(out_dir, "abort_trace.txt").encode())
+        lib.gf3_install_abort_trace.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        term = -1
+        try:                                             # the fd pytest's faulthandler plugin kept of the real stderr
+            from _pytest.faulthandler import fault_handler_stderr_fd_key
+            term = int(session.config.stash[fault_handler_stderr_fd_key])
+        except Exception:
+            pass
+        lib.gf3_install_abort_trace(os.path.join(out_dir, "abort_trace.txt").encode(), term)
         session.config._gf3_abort_trace = lib            # (keeps the library loaded)
     except Exception:
         pass
