@@ -105,6 +105,9 @@ class Gf3Error(RuntimeError):
     pass
 
 
+DIRECT_PIECE_BYTES = 128 << 20      # from this size on the runtime pins a pageable source on the fly (its GPU_PINNED_MIN_XFER_SIZE)
+
+
 def host_pieces(n, chunk_samples, Lc, L):
     """How Engine.receive_host cuts a stream of n samples (chirp length Lc, packet body L = M*S samples): a list of
     pieces, each dict(lo, hi: the NEW samples [lo, hi) it brings; base: stream index of the first sample of its device
@@ -521,6 +524,16 @@ class Engine:
         cfg = self.cfg
         n = x.numel()
         Lc, L = cfg.chirp_length, cfg.M * cfg.S
+        # Pageable memory, a large stream: pieces of at least 128 MiB, copied by the runtime itself.  From that size on a plain
+        # copy from pageable memory is pinned by the runtime on the fly and runs at the DMA rate (55 GB/s measured; below
+        # it, it is staged at 13-15 GB/s) -- the path every large host-to-device copy of every program takes.  The copy
+        # blocks the calling thread, so it does not run under the previous piece's kernels (0.75 ms per 128 MB).
+        direct = False
+        if not pinned_in and n * x.element_size() >= 2 * DIRECT_PIECE_BYTES:
+            direct = True
+            min_piece = -(-(DIRECT_PIECE_BYTES + 65536) // x.element_size())
+            k = max(1, min(n // min_piece, -(-n // max(int(chunk_samples), 1))))     # equal pieces, none below the threshold,
+            chunk_samples = -(-n // k)                                                # no more of them than were asked for
         pieces, H, carry = host_pieces(n, chunk_samples, Lc, L)  # carry: samples of the previous piece kept in front of a piece
         nchunks = len(pieces)
         plen = n + Lc - 1
@@ -532,7 +545,8 @@ class Engine:
         # Device buffers, workspace, pinned staging, the copy stream and its events are kept between calls (per host
         # thread: two threads may ingest through one Engine at once) and reused while the sizes fit: a receiver that is
         # fed one recording after another does not allocate per call.
-        key = (nbuf, cap_list, cap_peaks, bool(pinned_in), cfg.in_dtype, min(3, nchunks))
+        staging = not pinned_in and not direct
+        key = (nbuf, cap_list, cap_peaks, bool(staging), cfg.in_dtype, min(3, nchunks))
         res = getattr(self._tls, "ingest", None)
         if res is None or res["key"] != key:
             # (the copy stream is a HIGH-PRIORITY stream: the runtime multiplexes streams of one priority onto a handful of
@@ -541,14 +555,14 @@ class Engine:
             #  other streams existed; queues of another priority level are never shared with it)
             res = dict(key=key, copier=torch.cuda.Stream(dev, priority=-1),
                        bufs=[self._new((nbuf,), cfg.in_dtype) for _ in range(min(2, nchunks))],
-                       stage=None if pinned_in else [torch.empty((min(H, n),), dtype=cfg.in_dtype).pin_memory() for _ in range(min(3, nchunks))],
+                       stage=[torch.empty((min(H, n),), dtype=cfg.in_dtype).pin_memory() for _ in range(min(3, nchunks))] if staging else None,
                        idx_all=self._new((cap_list,), torch.int64), val_all=self._new((cap_list, 3), torch.float64),
                        work=self._new((int(self.lib.gf3_sync_chunk_workspace_bytes(self._h, nbuf)),), torch.uint8),
                        peaks_dev=self._new((cap_peaks,), torch.int64),
                        dwork=self._new((int(self.lib.gf3_sync_decide_workspace_bytes(self._h, cap_list)),), torch.uint8),
                        rows=self._new((cap_peaks, self.bytes_per_frame), torch.uint8))
             res["ev_copied"] = [torch.cuda.Event() for _ in res["bufs"]]
-            if not pinned_in:
+            if staging:
                 from concurrent.futures import ThreadPoolExecutor
                 res["pool"] = ThreadPoolExecutor(4)                # the four slices of one staging copy
                 res["stager"] = ThreadPoolExecutor(1)              # the staging copy of a piece, off the calling thread
@@ -561,7 +575,8 @@ class Engine:
         segs, overflow = [], []                                   # per piece: (first entry, entries) of the kept list; pieces whose list did not fit
         n_listed = 0
         BIG = (1 << 62)
-        info = dict(chunks=nchunks, chunk_samples=H, overlap_samples=carry, pinned_input=bool(pinned_in), pinned_in_place=bool(registered), h2d_bytes=0,
+        info = dict(chunks=nchunks, chunk_samples=H, overlap_samples=carry, pinned_input=bool(pinned_in), pinned_in_place=bool(registered),
+                    source="pinned" if pinned_in else ("pageable, copied by the runtime in large pieces" if direct else "pageable, staged"), h2d_bytes=0,
                     second_look_chunks=0, second_look_packets=0, provisional_detections_dropped=0, full_list_pieces=0)
 
         def geometry(c):
@@ -593,7 +608,8 @@ class Engine:
                 staged.pop(c).result()                            # (staged while the previous piece's kernels ran)
                 src = stage[c % 3][: hi_s - lo_s]
             with torch.cuda.stream(copier):
-                bufs[b][carry: carry + (hi_s - lo_s)].copy_(src, non_blocking=True)
+                # (pinned or staged source: asynchronous; `direct`: the source is pageable and torch makes the copy a blocking one)
+                bufs[b][carry: carry + (hi_s - lo_s)].copy_(src, non_blocking=not direct)
                 ev_copied[b].record(copier)
             info["h2d_bytes"] += (hi_s - lo_s) * x.element_size()
 

@@ -1517,6 +1517,28 @@ def test_receive_host_pins_a_large_pageable_array_in_place():
     assert torch.equal(small["peaks"], one[:41]) and torch.equal(small["bits"], out["bits"][:40])
 
 
+def test_receive_host_large_pageable_stream_is_copied_by_the_runtime():
+    """The default for pageable memory: a stream of 256 MiB or more is cut into equal pieces of at least 128 MiB and each
+    piece is handed to the runtime as it is (which pins a source of that size on the fly); smaller streams are staged.
+    1 400 config-3 packets (439 MB of f32): three pieces, the peaks and bits of the one-shot path, every sample over
+    PCIe once."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("config3_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "config3.py"))
+    tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
+    eng, cfg, channel = tool.make_engine()
+    r, payload = tool.make_stream(eng, channel, 1400, seed=13)
+    host = r.cpu().numpy().copy()
+    out = eng.receive_host(host)
+    info = out["info"]
+    assert info["source"].startswith("pageable, copied by the runtime") and info["chunks"] == 3 and not info["pinned_input"], info
+    assert info["chunk_samples"] * 4 >= (128 << 20) and info["h2d_bytes"] == host.nbytes, info
+    one = eng.sync_stream(r)
+    assert torch.equal(out["peaks"], one) and one.numel() == 1401
+    assert torch.equal(out["bits"], eng.demod_frames(r, (one + 2)[:-1])["bits"])
+    staged = eng.receive_host(host[: 64 + 800 * cfg.frame_len + cfg.chirp_length + 200].copy())      # 251 MB: staged
+    assert staged["info"]["source"] == "pageable, staged" and torch.equal(staged["peaks"], one[:801]), staged["info"]
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the screened frames-mode sync (gf3_sync_frames_ex mode 1; gf3rx_fscreen.h)
 # ---------------------------------------------------------------------------------------------------------------

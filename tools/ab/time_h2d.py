@@ -35,12 +35,12 @@ if FRAMES <= 4096:                                          # pageable input: pi
     t = float(np.median(ts[1:]))
     print("receive_host from PAGEABLE memory (pinned in place: %s): %.2f ms = %.1f GB/s, %.2f G samples/s; peaks equal: %s" % (
         res2["info"]["pinned_in_place"], t * 1e3, n * 4 / t / 1e9, n / t / 1e9, bool(torch.equal(res2["peaks"], res["peaks"]))), flush=True)
-if FRAMES <= 4096:                                          # ... and the fallback: staged through pinned buffers by host copies
+if FRAMES <= 4096:                                          # ... and the default for pageable memory (large streams: pieces of 128 MiB and more handed to the runtime; small ones staged)
     ts = []
     for _ in range(3):
         t = time.perf_counter(); res3 = eng.receive_host(pageable, chunk_samples=1 << 25, pin_in_place=False); ts.append(time.perf_counter() - t)
     t = float(np.median(ts[1:]))
-    print("receive_host from PAGEABLE memory, staged (fallback): %.2f ms = %.1f GB/s; peaks equal: %s" % (t * 1e3, n * 4 / t / 1e9, bool(torch.equal(res3["peaks"], res["peaks"]))), flush=True)
+    print("receive_host from PAGEABLE memory, default (%s): %.2f ms = %.1f GB/s; peaks equal: %s" % (res3["info"]["source"], t * 1e3, n * 4 / t / 1e9, bool(torch.equal(res3["peaks"], res["peaks"]))), flush=True)
 one = eng.sync_stream(r)
 print("peaks equal the one-shot path:", bool(torch.equal(one, res["peaks"])), " bits equal:", bool(torch.equal(eng.demod_frames(r, (one + 2)[:-1])["bits"], res["bits"])),
       " detections", int(one.numel()), res["info"])

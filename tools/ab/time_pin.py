@@ -22,6 +22,12 @@ def staged(threads):
 for th in (1, 4, 8, 16):
     staged(th); dt = staged(th)
     print("staged, %2d host thread(s): %.1f ms = %.1f GB/s" % (th, dt * 1e3, n * 4 / dt / 1e9), flush=True)
+for piece in (1 << 23, 1 << 25, 1 << 27):                       # the runtime's own path for pageable memory (it stages or pins by itself)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for lo in range(0, n, piece):
+        dst[lo:lo + piece].copy_(t_a[lo:lo + piece])
+    torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print("plain copy_ from the pageable array in pieces of %9d samples: %.1f ms = %.1f GB/s" % (piece, dt * 1e3, n * 4 / dt / 1e9), flush=True)
 rt = torch.cuda.cudart()
 t = time.perf_counter(); rc = rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0); t_reg = time.perf_counter() - t
 print("cudaHostRegister rc", rc, "%.1f ms" % (t_reg * 1e3), flush=True)
