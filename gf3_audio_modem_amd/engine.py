@@ -448,8 +448,9 @@ class Engine:
         kill an earlier candidate, or un-suppressed one) are packets looked at again -- their samples re-read from the
         host array.  Pieces overlap by Lc + one packet, so no chirp and no packet is cut.
 
-        samples: 1-D numpy array or CPU torch tensor.  A pinned tensor is copied from directly.  Pageable memory is staged
-        through THREE pinned buffers (below); with pin_in_place=True an array of at least pin_min_bytes -- 64 MiB: an
+        samples: 1-D numpy array or CPU torch tensor.  A pinned tensor is copied from directly.  Pageable memory of 256 MiB
+        and more goes to the runtime in equal pieces of at least 128 MiB (which it pins on the fly: the DMA rate, not
+        overlapped with the kernels); less than that is staged through THREE pinned buffers (below); with pin_in_place=True an array of at least pin_min_bytes -- 64 MiB: an
         allocation of that size is a mapping of its own, whose pages hold nothing else -- is instead registered with the
         driver for the duration of the call and copied from at the pinned rate (twice the staged one).  That is an opt-in:
         registering and releasing ranges of ordinary process memory over and over was followed, in this package's own test
