@@ -449,10 +449,11 @@ class Engine:
         host array.  Pieces overlap by Lc + one packet, so no chirp and no packet is cut.
 
         samples: 1-D numpy array or CPU torch tensor.  A pinned tensor is copied from directly.  Pageable memory of 256 MiB
-        and more goes to the runtime in equal pieces of at least 128 MiB (which it pins on the fly: the DMA rate, not
-        overlapped with the kernels); less than that is staged through THREE pinned buffers (below); with pin_in_place=True an array of at least pin_min_bytes -- 64 MiB: an
+        and more goes to the runtime in equal pieces of at least 128 MiB (which it pins on the fly: the DMA rate; a copy
+        thread makes these blocking copies under the previous piece's kernels); less than that is staged through THREE pinned buffers (below); with pin_in_place=True an array of at least pin_min_bytes -- 64 MiB: an
         allocation of that size is a mapping of its own, whose pages hold nothing else -- is instead registered with the
-        driver for the duration of the call and copied from at the pinned rate (twice the staged one).  That is an opt-in:
+        driver for the duration of the call and copied from at the pinned rate.  That is an opt-in (and no faster than the
+        default since the copy thread):
         registering and releasing ranges of ordinary process memory over and over was followed, in this package's own test
         runs, by GPU memory faults in unrelated kernels later in the process; read-only arrays and file
         mappings are never registered.  Staging: a host copy
@@ -512,6 +513,12 @@ class Engine:
         try:
             return self._receive_host(x, x.is_pinned() or registered, registered, chunk_samples, list_cap, t_start)
         except BaseException:
+            held = getattr(self._tls, "ingest", None) or {}
+            for fut in list(held.pop("pending", [])):              # copies still being made on a helper thread
+                try:
+                    fut.result()
+                except Exception:
+                    pass
             torch.cuda.synchronize(self.device)                    # nothing of the call is in flight when its buffers are let go
             raise
         finally:
@@ -527,8 +534,8 @@ class Engine:
         Lc, L = cfg.chirp_length, cfg.M * cfg.S
         # Pageable memory, a large stream: pieces of at least 128 MiB, copied by the runtime itself.  From that size on a plain
         # copy from pageable memory is pinned by the runtime on the fly and runs at the DMA rate (55 GB/s measured; below
-        # it, it is staged at 13-15 GB/s) -- the path every large host-to-device copy of every program takes.  The copy
-        # blocks the calling thread, so it does not run under the previous piece's kernels (0.75 ms per 128 MB).
+        # it, it is staged at 13-15 GB/s) -- the path every large host-to-device copy of every program takes.  Such a copy
+        # blocks its caller, so a copy thread makes it while the calling thread runs the previous piece's kernels.
         direct = False
         if not pinned_in and n * x.element_size() >= 2 * DIRECT_PIECE_BYTES:
             direct = True
@@ -547,7 +554,7 @@ class Engine:
         # thread: two threads may ingest through one Engine at once) and reused while the sizes fit: a receiver that is
         # fed one recording after another does not allocate per call.
         staging = not pinned_in and not direct
-        key = (nbuf, cap_list, cap_peaks, bool(staging), cfg.in_dtype, min(3, nchunks))
+        key = (nbuf, cap_list, cap_peaks, bool(staging), bool(direct), cfg.in_dtype, min(3, nchunks))
         res = getattr(self._tls, "ingest", None)
         if res is None or res["key"] != key:
             # (the copy stream is a HIGH-PRIORITY stream: the runtime multiplexes streams of one priority onto a handful of
@@ -563,6 +570,9 @@ class Engine:
                        dwork=self._new((int(self.lib.gf3_sync_decide_workspace_bytes(self._h, cap_list)),), torch.uint8),
                        rows=self._new((cap_peaks, self.bytes_per_frame), torch.uint8))
             res["ev_copied"] = [torch.cuda.Event() for _ in res["bufs"]]
+            if direct:
+                from concurrent.futures import ThreadPoolExecutor
+                res["copy_thread"] = ThreadPoolExecutor(1)         # makes the blocking copies, so that the kernels of the previous piece run under them
             if staging:
                 from concurrent.futures import ThreadPoolExecutor
                 res["pool"] = ThreadPoolExecutor(4)                # the four slices of one staging copy
@@ -585,6 +595,7 @@ class Engine:
             return q["lo"], q["hi"], q["lo"] - q["base"], q["base"], q["g_lo"], q["g_hi"]
 
         staged = {}                                               # piece -> future of its host-side staging copy
+        copies = {}                                               # piece -> future of its blocking copy (large pageable streams)
 
         def stage_piece(c):
             """pageable source, registration refused: piece c's new samples -> pinned staging buffer c % 3 (a host copy by
@@ -608,11 +619,19 @@ class Engine:
             if stage is not None:
                 staged.pop(c).result()                            # (staged while the previous piece's kernels ran)
                 src = stage[c % 3][: hi_s - lo_s]
-            with torch.cuda.stream(copier):
-                # (pinned or staged source: asynchronous; `direct`: the source is pageable and torch makes the copy a blocking one)
-                bufs[b][carry: carry + (hi_s - lo_s)].copy_(src, non_blocking=not direct)
-                ev_copied[b].record(copier)
             info["h2d_bytes"] += (hi_s - lo_s) * x.element_size()
+            if direct:
+                # the source is pageable: the copy blocks its caller while the runtime pins and transfers the piece -- so it is
+                # made on the copy thread (stream order: the wait for `ev_order` was enqueued by the calling thread before this)
+                def job(b=b, src=src, m=hi_s - lo_s):
+                    with torch.cuda.stream(copier):
+                        bufs[b][carry: carry + m].copy_(src)
+                        ev_copied[b].record(copier)
+                copies[c] = res["copy_thread"].submit(job)
+                return
+            with torch.cuda.stream(copier):
+                bufs[b][carry: carry + (hi_s - lo_s)].copy_(src, non_blocking=True)
+                ev_copied[b].record(copier)
 
         def sync_piece(buf, n_buf, lag_lo, lag_hi, base, idx_t, val_t, cap):
             """-> (entries listed, or -(entries wanted) - 1 when they do not fit; the piece's own maximum)"""
@@ -631,19 +650,23 @@ class Engine:
             return peaks_dev[: cnt.value].cpu().numpy()
 
         info["setup_seconds"] = time.perf_counter() - t_start    # (pinned staging, device buffers, workspace: cached by torch after the first call)
+        for fut in list(res.pop("pending", [])):                   # (a previous call that ended in an exception may have left copies running)
+            try:
+                fut.result()
+            except Exception:
+                pass
         if stage is not None:
-            for fut in res.pop("pending", []):                     # (a previous call that ended in an exception may have left copies running)
-                try:
-                    fut.result()
-                except Exception:
-                    pass
             for c0 in range(min(2, nchunks)):
                 staged[c0] = res["stager"].submit(stage_piece, c0)
             res["pending"] = staged.values()
+        if direct:
+            res["pending"] = copies.values()
         issue_copy(0)
         for c in range(nchunks):
             b = c % 2
             lo_s, hi_s, ce, base, g_lo, g_hi = geometry(c)
+            if direct:
+                copies.pop(c).result()                             # (the copy thread has recorded ev_copied[b])
             main.wait_event(ev_copied[b])
             if ce:
                 # (the previous piece was a full one: its last `ce` new samples sit at the end of its buffer)
