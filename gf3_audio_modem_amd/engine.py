@@ -434,7 +434,7 @@ class Engine:
         return llr
 
     # ------------------------------------------------------------------ host ingest (streams from host memory / longer than HBM)
-    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None, pin_in_place=False, pin_min_bytes=None):
+    def receive_host(self, samples, chunk_samples=1 << 24, list_cap=None):
         """chirp sync + demodulation (the arithmetic of receiver.receive, OFDM.py:581-603) of a stream that lives in
         HOST memory, piece by piece: pinned, double-buffered H2D copies on a copy stream run under the kernels of the
         previous piece, and the result is that of the one-shot path -- the reference's rule with the GLOBAL maximum
@@ -450,19 +450,16 @@ class Engine:
 
         samples: 1-D numpy array or CPU torch tensor.  A pinned tensor is copied from directly.  Pageable memory of 256 MiB
         and more goes to the runtime in equal pieces of at least 128 MiB (which it pins on the fly: the DMA rate; a copy
-        thread makes these blocking copies under the previous piece's kernels); less than that is staged through THREE pinned buffers (below); with pin_in_place=True an array of at least pin_min_bytes -- 64 MiB: an
-        allocation of that size is a mapping of its own, whose pages hold nothing else -- is instead registered with the
-        driver for the duration of the call and copied from at the pinned rate.  That is an opt-in (and no faster than the
-        default since the copy thread):
-        registering and releasing ranges of ordinary process memory over and over was followed, in this package's own test
-        runs, by GPU memory faults in unrelated kernels later in the process; read-only arrays and file
-        mappings are never registered.  Staging: a host copy
-        per piece that a background thread makes two pieces ahead of the kernels: under piece c's kernels and piece c+1's
-        DMA, piece c+2 is being staged -- into the buffer piece c-1 was copied from, which is idle by then, so the thread
-        makes no HIP call at all).  chunk_samples: new samples per piece (raised to
-        two packets if smaller).  Returns dict(peaks int64 [n_det] (device), bits uint8 [n_det - 1, bytes_per_frame]
-        (device, packed), info).  Raises ValueError where the reference fails (fewer than two detections; a packet that
-        runs past the end of the stream)."""
+        thread makes these blocking copies under the previous piece's kernels); less than that is staged through THREE
+        pinned buffers by a host copy per piece that a background thread makes two pieces ahead of the kernels: under piece
+        c's kernels and piece c+1's DMA, piece c+2 is being staged -- into the buffer piece c-1 was copied from, which is
+        idle by then, so that thread makes no HIP call at all.  (Until round 4 a pageable array could also be registered
+        with the driver -- hipHostRegister -- for the duration of the call.  Registering and releasing ordinary process
+        memory over and over was followed, in this package's own test runs, by GPU memory faults in unrelated kernels
+        later in the process, and the default is as fast now: removed)  chunk_samples: new samples per piece
+        (raised to two packets if smaller).  Returns dict(peaks int64 [n_det] (device), bits uint8 [n_det - 1,
+        bytes_per_frame] (device, packed), info).  Raises ValueError where the reference fails (fewer than two detections;
+        a packet that runs past the end of the stream)."""
         import time
         t_start = time.perf_counter()
         cfg = self.cfg
@@ -476,42 +473,14 @@ class Engine:
             a = np.asarray(samples).reshape(-1)
             want = torch.empty(0, dtype=cfg.in_dtype).numpy().dtype
             b = np.ascontiguousarray(a if a.dtype == want else a.astype(want))
-            # Only ordinary, writable process memory is pinned in place.  A read-only array or a file mapping (np.memmap) is
-            # staged instead: registering such a range asks the driver for write access to pages the process may not write,
-            # and a registration that outlives its mapping poisons whatever is mapped there next.
-            m = b
-            while isinstance(m, np.ndarray) and not isinstance(m, np.memmap) and m.base is not None:
-                m = m.base
-            if not b.flags.writeable or not isinstance(m, np.ndarray) or isinstance(m, np.memmap):
-                pin_in_place = False
             import warnings
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")                    # (torch warns when it wraps a non-writable array; it is only read)
                 x = torch.from_numpy(b)
-        n = x.numel()
-        if n < 3:
+        if x.numel() < 3:
             raise ValueError("stream too short")
-        # Nor is a small array: below glibc's largest mmap threshold (32 MiB) an allocation can be a piece of the heap, and
-        # registering it would hand pages that also hold unrelated objects -- the runtime's own among them -- to the driver.
-        if pin_min_bytes is None:
-            pin_min_bytes = int(os.environ.get("GF3_PIN_MIN_BYTES", 64 << 20))
-        if n * x.element_size() < int(pin_min_bytes):
-            pin_in_place = False
-        # Pageable input is PINNED IN PLACE for the duration of the call (hipHostRegister: 3 ms for 1.3 GB on the GPU box, after
-        # which the copies run at the pinned rate, 57 GB/s; staging every piece through a pinned buffer by a host copy runs at
-        # 4 GB/s on one thread).  Staging remains the fallback when the registration is refused.
-        registered = False
-        if pin_in_place and not x.is_pinned():
-            try:
-                registered = int(torch.cuda.cudart().cudaHostRegister(x.data_ptr(), n * x.element_size(), 0)) == 0
-            except Exception:
-                registered = False
-            if not registered:
-                # a refused registration (a read-only mapping, the locked-memory limit) leaves the runtime's sticky error
-                # set; cleared here, or the next launch check of the staging path would report it as its own
-                self.lib.gf3_clear_runtime_error()
         try:
-            return self._receive_host(x, x.is_pinned() or registered, registered, chunk_samples, list_cap, t_start)
+            return self._receive_host(x, x.is_pinned(), chunk_samples, list_cap, t_start)
         except BaseException:
             held = getattr(self._tls, "ingest", None) or {}
             for fut in list(held.pop("pending", [])):              # copies still being made on a helper thread
@@ -521,13 +490,8 @@ class Engine:
                     pass
             torch.cuda.synchronize(self.device)                    # nothing of the call is in flight when its buffers are let go
             raise
-        finally:
-            if registered:
-                torch.cuda.synchronize(self.device)
-                if int(torch.cuda.cudart().cudaHostUnregister(x.data_ptr())) != 0:
-                    self.lib.gf3_clear_runtime_error()
 
-    def _receive_host(self, x, pinned_in, registered, chunk_samples, list_cap, t_start):
+    def _receive_host(self, x, pinned_in, chunk_samples, list_cap, t_start):
         import time
         cfg = self.cfg
         n = x.numel()
@@ -586,7 +550,7 @@ class Engine:
         segs, overflow = [], []                                   # per piece: (first entry, entries) of the kept list; pieces whose list did not fit
         n_listed = 0
         BIG = (1 << 62)
-        info = dict(chunks=nchunks, chunk_samples=H, overlap_samples=carry, pinned_input=bool(pinned_in), pinned_in_place=bool(registered),
+        info = dict(chunks=nchunks, chunk_samples=H, overlap_samples=carry, pinned_input=bool(pinned_in),
                     source="pinned" if pinned_in else ("pageable, copied by the runtime in large pieces" if direct else "pageable, staged"), h2d_bytes=0,
                     second_look_chunks=0, second_look_packets=0, provisional_detections_dropped=0, full_list_pieces=0)
 
@@ -598,7 +562,7 @@ class Engine:
         copies = {}                                               # piece -> future of its blocking copy (large pageable streams)
 
         def stage_piece(c):
-            """pageable source, registration refused: piece c's new samples -> pinned staging buffer c % 3 (a host copy by
+            """pageable source, a small stream: piece c's new samples -> pinned staging buffer c % 3 (a host copy by
             four threads).  Runs on the stager thread, TWO pieces ahead of the kernels -- under piece c - 2's kernels and
             piece c - 1's DMA.  The buffer was last read by the DMA of piece c - 3, which the calling thread has seen
             finish (it synchronised on piece c - 3's kernels, which waited for that DMA) before it submits this: a plain

@@ -1154,8 +1154,7 @@ def _config1_case():
 @pytest.mark.parametrize("storage", ["f64_pageable", "f32_pinned"])
 def test_receive_host_chunked_equals_one_shot_and_reference(storage):
     """BASELINE config 1 (64 frames, the reference's own bits in the g1b fixture) from HOST memory in 33 pieces of
-    two packets each -- pageable (staged through pinned buffers two pieces ahead; pinning in place is an opt-in for large
-    arrays, test_receive_host_pins_a_large_pageable_array_in_place) and pinned -- : peaks and bits of the
+    two packets each -- pageable (staged through pinned buffers two pieces ahead) and pinned -- : peaks and bits of the
     one-shot device path and of the reference."""
     g, p, F, r = _config1_case()
     dt = torch.float64 if storage.startswith("f64") else torch.float32
@@ -1167,7 +1166,7 @@ def test_receive_host_chunked_equals_one_shot_and_reference(storage):
         host, ref_bits = r, unpack(g)
     out = eng.receive_host(host, chunk_samples=1)                       # (raised to two packets per piece)
     info = out["info"]
-    assert info["chunks"] >= 4 and info["pinned_input"] == (storage == "f32_pinned") and not info["pinned_in_place"], info
+    assert info["chunks"] >= 4 and info["pinned_input"] == (storage == "f32_pinned") and info["source"] == ("pinned" if storage == "f32_pinned" else "pageable, staged"), info
     x = torch.as_tensor(host).cuda()
     one = eng.sync_stream(x)
     assert torch.equal(out["peaks"], one) and out["peaks"].numel() == F + 1
@@ -1442,12 +1441,10 @@ def test_unpack_decode_kernel_matches_numpy(C, mu, D):
     assert rc == -1 and b"pinned" in eng.lib.gf3_last_error(None)
 
 
-def test_receive_host_list_exactly_full_and_refused_registration(tmp_path):
+def test_receive_host_list_exactly_full_and_read_only_mapping(tmp_path):
     """ (i) a kept-lag list that is EXACTLY full when a piece begins: the piece is offered no room (cap 0, no
     buffers) and is either empty or overflows into the second look -- for every capacity from 1 to the number of lags
-    the stream keeps, the detections and bits are the oracle's; (ii) a read-only file mapping is staged, never pinned in
-    place; a registration the runtime refuses is cleared, the staging path (host copies two pieces ahead, on a background
-    thread) gives the same result, and the next unrelated launch sees no stale error."""
+    the stream keeps, the detections and bits are the oracle's; (ii) a read-only file mapping as the source."""
     g = load("g1_n1024_qpsk")
     p = params_of(g)
     r, payload = _crafted_stream(p, 50)
@@ -1465,56 +1462,17 @@ def test_receive_host_list_exactly_full_and_refused_registration(tmp_path):
         assert torch.equal(out["bits"], base["bits"]), cap
     assert full >= 1                                                    # some capacity left a piece no room at all
     assert np.array_equal(eng.unpack_bits(base["bits"]).cpu().numpy(), ref["bits"])
-    # (ii) a read-only file mapping is never pinned in place (the staging path takes it) ...
+    # (ii) a read-only file mapping is taken like any other pageable array (staged: host copies two pieces ahead, on a
+    #      background thread), and nothing is left behind for the next launch check
     path = tmp_path / "stream.f64"
     r.tofile(path)
     ro = np.memmap(path, dtype=np.float64, mode="r")
-    out = eng.receive_host(ro, chunk_samples=1, pin_in_place=True, pin_min_bytes=0)
-    assert not out["info"]["pinned_in_place"] and not out["info"]["pinned_input"], out["info"]
+    out = eng.receive_host(ro, chunk_samples=1)
+    assert out["info"]["source"] == "pageable, staged" and out["info"]["chunks"] >= 4 and not out["info"]["pinned_input"], out["info"]
     assert np.array_equal(out["peaks"].cpu().numpy(), want_peaks) and torch.equal(out["bits"], base["bits"])
     del ro
-    # ... and a registration the runtime REFUSES (here: made to fail) is cleared and falls back to staging as well
-    class _Refusing:
-        def __init__(self, rt): self.rt = rt
-        def cudaHostRegister(self, ptr, size, flags):
-            return self.rt.cudaHostRegister(0, 4096, 0)                 # a NULL range: a real refusal, with its real sticky error
-        def __getattr__(self, k): return getattr(self.rt, k)
-    real = torch.cuda.cudart
-    torch.cuda.cudart = lambda: _Refusing(real())
-    try:
-        out = eng.receive_host(r, chunk_samples=1, pin_in_place=True, pin_min_bytes=0)
-    finally:
-        torch.cuda.cudart = real
-    assert not out["info"]["pinned_in_place"], out["info"]
-    assert np.array_equal(out["peaks"].cpu().numpy(), want_peaks) and torch.equal(out["bits"], base["bits"])
-    assert eng.lib.gf3_clear_runtime_error() == 0                       # nothing left behind for the next launch check
+    assert eng.lib.gf3_clear_runtime_error() == 0
     assert torch.equal(eng.sync_stream(torch.from_numpy(r).cuda()), out["peaks"])
-    staged = eng.receive_host(r, chunk_samples=1, pin_in_place=False)   # the fallback itself, forced: many pieces, pipeline two ahead
-    assert staged["info"]["chunks"] >= 4 and not staged["info"]["pinned_input"]
-    assert torch.equal(staged["peaks"], out["peaks"]) and torch.equal(staged["bits"], base["bits"])
-
-
-def test_receive_host_pins_a_large_pageable_array_in_place():
-    """Opt-in (pin_in_place=True): a pageable array of 64 MiB or more (a mapping of its own) is registered for the duration of
-    the call and copied from at the pinned rate: 256 config-3 packets (80 MB of f32) in 20 pieces -- the peaks and bits of the one-shot path,
-    every sample over PCIe once, the registration gone afterwards."""
-    import importlib.util, os
-    spec = importlib.util.spec_from_file_location("config3_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "config3.py"))
-    tool = importlib.util.module_from_spec(spec); spec.loader.exec_module(tool)
-    eng, cfg, channel = tool.make_engine()
-    r, payload = tool.make_stream(eng, channel, 256, seed=11)
-    host = r.cpu().numpy().copy()                                      # (an array that owns its memory, as wavfile.read returns)
-    assert host.nbytes >= 64 << 20 and not torch.from_numpy(host).is_pinned()
-    out = eng.receive_host(host, chunk_samples=1 << 20, pin_in_place=True)
-    info = out["info"]
-    assert info["pinned_in_place"] and info["pinned_input"] and info["chunks"] >= 16 and info["h2d_bytes"] == host.nbytes, info
-    assert not torch.from_numpy(host).is_pinned()                      # unregistered again
-    one = eng.sync_stream(r)
-    assert torch.equal(out["peaks"], one) and one.numel() == 257
-    assert torch.equal(out["bits"], eng.demod_frames(r, (one + 2)[:-1])["bits"])
-    small = eng.receive_host(host[: 64 + 40 * cfg.frame_len + cfg.chirp_length + 200].copy(), chunk_samples=1 << 20, pin_in_place=True)   # 12.6 MB: staged all the same
-    assert not small["info"]["pinned_in_place"] and not small["info"]["pinned_input"]
-    assert torch.equal(small["peaks"], one[:41]) and torch.equal(small["bits"], out["bits"][:40])
 
 
 def test_receive_host_large_pageable_stream_is_copied_by_the_runtime():

@@ -27,18 +27,11 @@ for chunk in (1 << 24, 1 << 25, 1 << 26, 1 << 27):
     i = res["info"]
     print("receive_host chunk %10d: %.2f ms = %.1f GB/s, %.2f G samples/s, pieces %d (last call: setup %.2f, pieces %.2f, total %.2f ms)" % (
         chunk, t * 1e3, n * 4 / t / 1e9, n / t / 1e9, i["chunks"], i["setup_seconds"] * 1e3, i["pieces_seconds"] * 1e3, i["seconds"] * 1e3), flush=True)
-if FRAMES <= 4096:                                          # pageable input: pinned in place for the call (staging through pinned buffers is the fallback)
-    pageable = host.numpy().copy()
-    ts = []
-    for _ in range(3):
-        t = time.perf_counter(); res2 = eng.receive_host(pageable, chunk_samples=1 << 25, pin_in_place=True); ts.append(time.perf_counter() - t)
-    t = float(np.median(ts[1:]))
-    print("receive_host from PAGEABLE memory (pinned in place: %s): %.2f ms = %.1f GB/s, %.2f G samples/s; peaks equal: %s" % (
-        res2["info"]["pinned_in_place"], t * 1e3, n * 4 / t / 1e9, n / t / 1e9, bool(torch.equal(res2["peaks"], res["peaks"]))), flush=True)
+pageable = host.numpy().copy() if FRAMES <= 4096 else None
 if FRAMES <= 4096:                                          # ... and the default for pageable memory (large streams: pieces of 128 MiB and more handed to the runtime; small ones staged)
     ts = []
     for _ in range(3):
-        t = time.perf_counter(); res3 = eng.receive_host(pageable, chunk_samples=1 << 25, pin_in_place=False); ts.append(time.perf_counter() - t)
+        t = time.perf_counter(); res3 = eng.receive_host(pageable, chunk_samples=1 << 25); ts.append(time.perf_counter() - t)
     t = float(np.median(ts[1:]))
     print("receive_host from PAGEABLE memory, default (%s): %.2f ms = %.1f GB/s; peaks equal: %s" % (res3["info"]["source"], t * 1e3, n * 4 / t / 1e9, bool(torch.equal(res3["peaks"], res["peaks"]))), flush=True)
 one = eng.sync_stream(r)
