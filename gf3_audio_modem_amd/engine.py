@@ -448,7 +448,7 @@ class Engine:
         kill an earlier candidate, or un-suppressed one) are packets looked at again -- their samples re-read from the
         host array.  Pieces overlap by Lc + one packet, so no chirp and no packet is cut.
 
-        samples: 1-D numpy array or CPU torch tensor.  A pinned tensor is copied from directly.  Pageable memory of 256 MiB
+        samples: 1-D numpy array or CPU torch tensor.  A pinned tensor is copied from directly.  Pageable memory of 128 MiB
         and more goes to the runtime in equal pieces of at least 128 MiB (which it pins on the fly: the DMA rate; a copy
         thread makes these blocking copies under the previous piece's kernels); less than that is staged through THREE
         pinned buffers by a host copy per piece that a background thread makes two pieces ahead of the kernels: under piece
@@ -501,7 +501,7 @@ class Engine:
         # it, it is staged at 13-15 GB/s) -- the path every large host-to-device copy of every program takes.  Such a copy
         # blocks its caller, so a copy thread makes it while the calling thread runs the previous piece's kernels.
         direct = False
-        if not pinned_in and n * x.element_size() >= 2 * DIRECT_PIECE_BYTES:
+        if not pinned_in and n * x.element_size() >= DIRECT_PIECE_BYTES + 65536:
             direct = True
             min_piece = -(-(DIRECT_PIECE_BYTES + 65536) // x.element_size())
             k = max(1, min(n // min_piece, -(-n // max(int(chunk_samples), 1))))     # equal pieces, none below the threshold,

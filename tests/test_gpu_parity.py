@@ -1476,7 +1476,7 @@ def test_receive_host_list_exactly_full_and_read_only_mapping(tmp_path):
 
 
 def test_receive_host_large_pageable_stream_is_copied_by_the_runtime():
-    """The default for pageable memory: a stream of 256 MiB or more is cut into equal pieces of at least 128 MiB and each
+    """The default for pageable memory: a stream of 128 MiB or more is cut into equal pieces of at least 128 MiB and each
     piece is handed to the runtime as it is (which pins a source of that size on the fly); smaller streams are staged.
     1 400 config-3 packets (439 MB of f32): three pieces, the peaks and bits of the one-shot path, every sample over
     PCIe once."""
@@ -1493,8 +1493,11 @@ def test_receive_host_large_pageable_stream_is_copied_by_the_runtime():
     one = eng.sync_stream(r)
     assert torch.equal(out["peaks"], one) and one.numel() == 1401
     assert torch.equal(out["bits"], eng.demod_frames(r, (one + 2)[:-1])["bits"])
-    staged = eng.receive_host(host[: 64 + 800 * cfg.frame_len + cfg.chirp_length + 200].copy())      # 251 MB: staged
-    assert staged["info"]["source"] == "pageable, staged" and torch.equal(staged["peaks"], one[:801]), staged["info"]
+    single = eng.receive_host(host[: 64 + 800 * cfg.frame_len + cfg.chirp_length + 200].copy())      # 251 MB: one piece, the runtime's
+    assert single["info"]["source"].startswith("pageable, copied by the runtime") and single["info"]["chunks"] == 1, single["info"]
+    assert torch.equal(single["peaks"], one[:801]) and torch.equal(single["bits"], out["bits"][:800])
+    staged = eng.receive_host(host[: 64 + 300 * cfg.frame_len + cfg.chirp_length + 200].copy())      # 94 MB: staged
+    assert staged["info"]["source"] == "pageable, staged" and torch.equal(staged["peaks"], one[:301]), staged["info"]
 
 
 # ---------------------------------------------------------------------------------------------------------------
